@@ -1,0 +1,339 @@
+/*
+ * mfsr.h -- C-ABI of the MI355X-native multi-frame super-resolution hot path.
+ *
+ * Drop-in boundary for the align -> fuse -> upsample path of
+ * zhongzisha/multi_frame_super_resolution (the ImageStackAlignator CUDA
+ * kernels in test_opencv, the five .cu files).  The reference exposes that path as
+ * unmangled `extern "C" __global__` symbols loaded by name by a host that is
+ * not in the repository, and its own host-side FFI convention is
+ * `extern "C" void f(T* devPtr..., int width, int height...)`
+ * (test_opencv/myKernels.cu:114-120,156-165; decls test_opencv/main.cpp:763-767).
+ * Each entry point below replaces the launch of ONE reference kernel: same
+ * name (prefixed mfsr_), same argument order, same units (pitches in BYTES,
+ * dims in elements, raw device pointers), with
+ *   - cudaTextureObject_t  ->  mfsr_tex2d {ptr, pitch, width, height} by value
+ *     (linear filtering, normalised coordinates; MIRROR addressing for images,
+ *     CLAMP for flow / parameter fields -- stated per function),
+ *   - the module constant c_cfaPattern -> mfsr_set_cfa_pattern(),
+ *   - grid/block shapes chosen by the library,
+ *   - one trailing mfsr_stream_t (a hipStream_t; NULL = default stream).
+ *
+ * Conventions (reference error convention: cudaError_t return + fprintf(stderr),
+ * test_opencv/kernel.cu:36-114):
+ *   - every function returns int: 0 = success, >0 = hipError_t, <0 = MFSR_E_*;
+ *     nothing throws; failures are logged to stderr;
+ *   - all calls are asynchronous on `stream` unless named *_sync;
+ *   - the caller allocates and frees every buffer; kernels never allocate;
+ *     accumulators are zero-initialised by the caller and accumulated across
+ *     calls (DeBayerKernels.cu:306-307,374-375);
+ *   - untouched border rings (caller initialises): deBayer* 2 px,
+ *     accumulate* 1 px, lucasKanadeOptim halfWindowSize px,
+ *     ComputeRobustnessMask 1 px.
+ *   - there is NO CPU fallback: without a HIP device every call fails.
+ */
+#ifndef MFSR_H
+#define MFSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFSR_VERSION 100
+
+typedef void* mfsr_stream_t; /* hipStream_t */
+
+typedef struct { float x, y; } mfsr_float2;
+typedef struct { float x, y, z; } mfsr_float3;
+typedef struct { float x, y, z, w; } mfsr_float4;
+
+/* stand-in for cudaTextureObject_t: pitched 2-D array in device memory */
+typedef struct {
+    const void* ptr;
+    int32_t pitch; /* bytes */
+    int32_t width; /* texels */
+    int32_t height;
+} mfsr_tex2d;
+
+enum {
+    MFSR_OK = 0,
+    MFSR_E_INVALID = -1,   /* bad argument (null pointer, non-positive size, pitch too small) */
+    MFSR_E_UNSUPPORTED = -2, /* parameter outside what the kernels are built for */
+    MFSR_E_NODEVICE = -3,  /* no usable HIP device */
+    MFSR_E_WORKSPACE = -4  /* workspace too small */
+};
+
+/* enum BayerColor, DeBayerKernels.cu:28-37 */
+enum { MFSR_RED = 0, MFSR_GREEN = 1, MFSR_BLUE = 2, MFSR_CYAN = 3, MFSR_MAGENTA = 4, MFSR_YELLOW = 5, MFSR_WHITE = 6 };
+
+const char* mfsr_error_string(int code);
+int mfsr_version(void);
+/* number of visible HIP devices (0 if none); never fails */
+int mfsr_device_count(void);
+
+/* ---- A0: c_cfaPattern[2][2], DeBayerKernels.cu:40-41 ---------------------- */
+/* pattern[0..3] = {[0][0],[0][1],[1][0],[1][1]}; RGGB = {0,1,1,2}.  Process-
+ * wide state like the reference's module constant; read at launch time. */
+int mfsr_set_cfa_pattern(const int32_t pattern[4]);
+int mfsr_get_cfa_pattern(int32_t pattern[4]);
+
+/* ---- A: DeBayerKernels.cu ------------------------------------------------- */
+/* A1 deBayersSubSample3 :244 -- dimX,dimY = OUTPUT (half-res) dims; dataIn is
+ * dense u16 with row stride 2*dimX elements. */
+int mfsr_deBayersSubSample3(const uint16_t* dataIn, mfsr_float3* imgOut, float maxVal, int dimX, int dimY, int strideOut,
+                            mfsr_stream_t stream);
+/* A2 deBayerGreenKernel :55 */
+int mfsr_deBayerGreenKernel(int width, int height, const float* imgIn, int strideIn, mfsr_float3* outImage,
+                            int strideOut, mfsr_float3 blackPoint, mfsr_float3 scale, mfsr_stream_t stream);
+/* A3 deBayerRedBlueKernel :153 (run after A2 has completed on the stream) */
+int mfsr_deBayerRedBlueKernel(int width, int height, const float* imgIn, int strideIn, mfsr_float3* outImage,
+                              int strideOut, mfsr_float3 blackPoint, mfsr_float3 scale, mfsr_stream_t stream);
+/* G1 accumulateImages :290 (x1 merge; kernelParam rows use strideOut, :308) */
+int mfsr_accumulateImages(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                          const mfsr_float4* certaintyMask, const mfsr_float3* kernelParam, const mfsr_float2* shifts,
+                          mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int strideOut,
+                          int strideMask, int strideShift, mfsr_stream_t stream);
+/* G2 accumulateImagesSuperRes :379 (x2 merge, output grid dimX x dimY covering
+ * the central half of the frame).  kernelParam: float4 texture, shifts: float2
+ * texture, both CLAMP.  strideKernelParam/strideShift of the reference are
+ * carried inside the descriptors. */
+int mfsr_accumulateImagesSuperRes(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                                  const mfsr_float4* certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts,
+                                  mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int strideOut,
+                                  int strideMask, mfsr_stream_t stream);
+/* G2 generalised to integer scale s (1..8) on the FULL frame: output grid
+ * (s*dimX) x (s*dimY); the build's extension of :379-468. */
+int mfsr_accumulateSuperResFull(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                                const mfsr_float4* certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts,
+                                mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int scale,
+                                int strideOut, int strideMask, mfsr_stream_t stream);
+
+/* ---- B/E/H/I: kernel.cu --------------------------------------------------- */
+int mfsr_squaredSum(const float* inTiles, float* outValues, int maxShift, int tileSize, int tileCount,
+                    mfsr_stream_t stream); /* :119 */
+int mfsr_boxFilterWithBorderX(const float* inTiles, float* outTiles, int maxShift, int tileSize, int tileCount,
+                              mfsr_stream_t stream); /* :149 */
+int mfsr_boxFilterWithBorderY(const float* inTiles, float* outTiles, int maxShift, int tileSize, int tileCount,
+                              mfsr_stream_t stream); /* :186 */
+int mfsr_normalizedCC(const float* ccImage, const float* squaredTemplate, const float* boxFilteredImage,
+                      float* shiftImage, int maxShift, int tileSize, int tileCount, mfsr_stream_t stream); /* :227 */
+int mfsr_convertToTilesOverlapBorder(const float* inImg, float* outTiles, int imgWidth, int imgHeight, int imgPitch,
+                                     int maxShift, int tileSize, int tileCountX, int tileCountY, mfsr_float2 baseShift,
+                                     float baseRotation, mfsr_stream_t stream); /* :265 */
+int mfsr_convertToTilesOverlapPreShift(const float* inImg, float* outTiles, const mfsr_float2* preShift,
+                                       int preShiftPitch, int imgWidth, int imgHeight, int imgPitch, int maxShift,
+                                       int tileSize, int tileCountX, int tileCountY, mfsr_float2 baseShift,
+                                       float baseRotation, mfsr_stream_t stream); /* :324 */
+int mfsr_GammasRGB(mfsr_float3* inOutImg, int imgWidth, int imgHeight, int imgPitch, mfsr_stream_t stream); /* :393 */
+int mfsr_ApplyWeighting(mfsr_float3* inOutImg, const mfsr_float3* finalImg, const mfsr_float3* weight, int imgWidth,
+                        int imgHeight, int imgPitch, float threshold, mfsr_stream_t stream); /* :426 */
+int mfsr_conjugateComplexMulKernel(const mfsr_float2* aIn, mfsr_float2* bInOut, int maxElem,
+                                   mfsr_stream_t stream); /* :485 */
+int mfsr_findMinimum(const float* shiftImage, mfsr_float2* coordinates, int coordinatesPitch, int maxShift,
+                     int tileCount, int tileCountX, float threshold, mfsr_stream_t stream); /* :512 */
+int mfsr_UpSampleShifts(const mfsr_float2* inShift, mfsr_float2* outShift, int inPitch, int outPitch, int oldLevel,
+                        int newLevel, int oldCountX, int oldCountY, int newCountX, int newCountY, int oldTileSize,
+                        int newTileSize, mfsr_stream_t stream); /* :642 */
+int mfsr_ComputeStructureTensor(const float* imgDx, const float* imgDy, mfsr_float3* outImg, int imgWidth,
+                                int imgHeight, int imgDxDyPitch, int imgOutPitch, mfsr_stream_t stream); /* :691 */
+int mfsr_ComputeKernelParam(mfsr_float3* kernelImg, int imgWidth, int imgHeight, int imgOutPitch, float Dth, float Dtr,
+                            float kDetail, float kDenoise, float kStretch, float kShrink,
+                            mfsr_stream_t stream); /* :718 */
+int mfsr_fourierFilter(mfsr_float2* img, size_t stride, int width, int height, float lp, float hp, float lps,
+                       float hps, int clearAxis, mfsr_stream_t stream);                             /* :794 */
+int mfsr_fftshift(mfsr_float2* fft, int width, int height, mfsr_stream_t stream); /* :873 */
+
+/* ---- C: ShiftMinimizerKernels.cu ------------------------------------------ */
+int mfsr_copyShiftMatrix(float* matrices, int tileCount, int imageCount, int shiftCount,
+                         mfsr_stream_t stream); /* :29 */
+int mfsr_setPointers(float** shiftMatrixArray, float** shiftMatrixSafeArray, float** matrixSquareArray,
+                     float** matrixInvertedArray, float** solvedMatrixArray, mfsr_float2** shiftOneToOneArray,
+                     mfsr_float2** shiftMeasuredArray, mfsr_float2** shiftOptimArray, float* shiftMatrices,
+                     float* shiftSafeMatrices, float* matricesSquared, float* matricesInverted, float* solvedMatrices,
+                     mfsr_float2* shiftsOneToOne, mfsr_float2* shiftsMeasured, mfsr_float2* shiftsOptim, int tileCount,
+                     int imageCount, int shiftCount, mfsr_stream_t stream); /* :51 */
+int mfsr_checkForOutliers(mfsr_float2* measuredShifts, const float* optimShiftsT, float* shiftMatrix, int* status,
+                          int* inversionInfo, int tileCount, int imageCount, int shiftCount,
+                          mfsr_stream_t stream); /* :81 */
+int mfsr_transposeShifts(mfsr_float2* measuredShifts, const float* measuredShiftsT, const float* shiftsOneToOneT,
+                         mfsr_float2* shiftsOneToOne, int tileCount, int imageCount, int shiftCount,
+                         mfsr_stream_t stream); /* :143 */
+int mfsr_getOptimalShifts(mfsr_float2* optimalShifts, const mfsr_float2* bestShifts, int imageCount, int tileCountX,
+                          int tileCountY, int optimalShiftsPitch, int referenceImage, int imageToTrack,
+                          mfsr_stream_t stream); /* :179 */
+int mfsr_concatenateShifts(const mfsr_float2* const* shiftIn, int* shiftInPitch, mfsr_float2* shiftOut, int shiftCount,
+                           int tileCountX, int tileCountY, mfsr_stream_t stream); /* :223 */
+int mfsr_separateShifts(const mfsr_float2* shiftIn, mfsr_float2* const* shiftOut, int* shiftOutPitch, int shiftCount,
+                        int tileCountX, int tileCountY, mfsr_stream_t stream); /* :242 */
+/* C4: the batched least-squares solve the reference leaves to a missing host
+ * (batched cuBLAS upstream): per tile d = (A^T A)^-1 A^T b, o = A d.  A is
+ * column-major m x (imageCount-1) per tile; optimShiftsT is planar
+ * [x(m) | y(m)] per tile (what checkForOutliers reads, :114-115);
+ * inversionInfo = 0 or (index of the zero pivot)+1.  imageCount-1 <= 63. */
+int mfsr_solveShiftsBatched(const float* shiftMatrix, const mfsr_float2* measuredShifts, mfsr_float2* shiftsOneToOne,
+                            float* optimShiftsT, int* inversionInfo, int tileCount, int imageCount, int shiftCount,
+                            mfsr_stream_t stream);
+
+/* C driver: iterate solve -> checkForOutliers until every tile's status is -1
+ * (at most shiftCount+1 rounds; synchronises the stream once per round to read
+ * the status array back).  status / inversionInfo: device int[tileCount]. */
+int mfsr_minimizeShifts(float* shiftMatrix, mfsr_float2* measuredShifts, mfsr_float2* shiftsOneToOne,
+                        float* optimShiftsT, int* status, int* inversionInfo, int tileCount, int imageCount,
+                        int shiftCount, int* roundsOut, mfsr_stream_t stream);
+
+/* ---- D/E: opticalFlow.cu -------------------------------------------------- */
+/* texUV: CLAMP; texToWarp: MIRROR */
+int mfsr_WarpingKernel(int width, int height, int stride, mfsr_tex2d texUV, float* out, mfsr_tex2d texToWarp,
+                       mfsr_stream_t stream); /* :28 */
+/* texObjShiftXY: CLAMP, tileCountX x tileCountY texels */
+int mfsr_CreateFlowFieldFromTiles(mfsr_float2* outImg, mfsr_tex2d texObjShiftXY, int tileSize, int tileCountX,
+                                  int tileCountY, int imgWidth, int imgHeight, int imgPitch, mfsr_float2 baseShift,
+                                  float baseRotation, mfsr_stream_t stream); /* :48 */
+/* texSource/texTarget: MIRROR, width x height */
+int mfsr_ComputeDerivativesKernel(int width, int height, int stride, float* Ix, float* Iy, float* Iz,
+                                  mfsr_tex2d texSource, mfsr_tex2d texTarget, mfsr_stream_t stream); /* :97 */
+int mfsr_ComputeDerivatives2Kernel(int width, int height, int stride, float* Ix, float* Iy, mfsr_tex2d tex,
+                                   mfsr_stream_t stream); /* :151 */
+int mfsr_lucasKanadeOptim(mfsr_float2* shifts, const float* imFx, const float* imFy, const float* imFt, int pitchShift,
+                          int pitchImg, int width, int height, int halfWindowSize, float minDet,
+                          mfsr_stream_t stream); /* :190 */
+
+/* ---- F: RobustnessModell.cu ----------------------------------------------- */
+/* texUV: CLAMP */
+int mfsr_ComputeRobustnessMask(const mfsr_float3* rawImgRef, const mfsr_float3* rawImgMoved,
+                               mfsr_float4* robustnessMask, mfsr_tex2d texUV, int imgWidth, int imgHeight, int imgPitch,
+                               int maskPitch, float alpha, float beta, float thresholdM,
+                               mfsr_stream_t stream); /* :29 */
+
+/* ---- host helpers of the reference ---------------------------------------- */
+/* gaussin_filter_1D, test_opencv/main.cpp:370-391; taps must hold 99 floats;
+ * returns the tap count (host function, no device work). */
+int mfsr_gaussin_filter_1D(float sigma, float* taps);
+/* sharpenImg2, finalProject/Project/multi_frame_sr.cpp:90-119 on DEVICE u8
+ * interleaved images (step in bytes); never-written pixels are 0. */
+int mfsr_sharpenImg2(const uint8_t* img, uint8_t* result, int rows, int cols, int ch, int stepIn, int stepOut,
+                     mfsr_stream_t stream);
+
+/* ---- glue stages between the reference kernels (the build's own; the
+ *      reference has no host for this path -- DESIGN.md "Pipeline glue") ---- */
+int mfsr_rgbToGray(const mfsr_float3* in, int inPitch, float* out, int outPitch, int width, int height,
+                   mfsr_stream_t stream);
+int mfsr_u16ToFloat(const uint16_t* in, float* out, int outPitch, int width, int height, float factor,
+                    mfsr_stream_t stream);
+/* separable filter, clamped borders, chan = 1 or 3, ntaps <= 99 (taps on HOST) */
+int mfsr_separableFilter(const float* in, int inPitch, float* tmp, float* out, int outPitch, int width, int height,
+                         int chan, const float* taps, int ntaps, mfsr_stream_t stream);
+int mfsr_downsample2x(const float* in, int inPitch, float* out, int outPitch, int outW, int outH, mfsr_stream_t stream);
+/* direct correlation replacing FFT -> conjugateComplexMulKernel -> IFFT; output
+ * in the wrapped layout normalizedCC reads (kernel.cu:248-254) */
+int mfsr_crossCorrelateTiles(const float* refTiles, const float* movedTiles, float* ccImage, int maxShift, int tileSize,
+                             int tileCount, mfsr_stream_t stream);
+int mfsr_addRoundedPreShift(const mfsr_float2* preShift, int prePitch, mfsr_float2* found, int foundPitch, int countX,
+                            int countY, mfsr_stream_t stream);
+int mfsr_scaleFlow(mfsr_float2* flow, int pitch, int width, int height, float factor, mfsr_stream_t stream);
+int mfsr_float3ToFloat4(const mfsr_float3* in, int inPitch, mfsr_float4* out, int outPitch, int width, int height,
+                        mfsr_stream_t stream);
+int mfsr_resampleFloat3(const mfsr_float3* in, int inPitch, int inW, int inH, mfsr_float3* out, int outPitch, int outW,
+                        int outH, float u0, float u1, float v0, float v1, mfsr_stream_t stream);
+/* exactly one of out16/out8 non-NULL; dense interleaved RGB */
+int mfsr_quantize(const mfsr_float3* in, int inPitch, uint16_t* out16, uint8_t* out8, int width, int height,
+                  float maxOut, mfsr_stream_t stream);
+int mfsr_fill_f32(float* dst, size_t count, float value, mfsr_stream_t stream);
+/* test hook for the accumulate kernels: 1 (default) evaluates exp(-w/2) with
+ * v_exp_f32, 0 with the ocml expf (tight parity against the oracle). */
+int mfsr_set_accumulate_fast_exp(int enable);
+
+/* ---- fused MI355X kernels (same results as the chains they replace, within
+ *      the tolerances stated in DESIGN.md) --------------------------------- */
+/* B1+B2+B3+B4+cc+B6+B7 in one launch, one workgroup per tile: gathers the
+ * reference tile and the pre-shifted moved patch into LDS, evaluates the L2
+ * distance image directly and reduces it with wavefront shuffles. */
+int mfsr_trackTilesFused(const float* refImg, const float* movedImg, const mfsr_float2* preShift, int preShiftPitch,
+                         mfsr_float2* coordinates, int coordinatesPitch, int imgWidth, int imgHeight, int imgPitch,
+                         int maxShift, int tileSize, int tileCountX, int tileCountY, float threshold,
+                         mfsr_stream_t stream);
+/* D2+D3+D4 for one Lucas-Kanade iteration in one launch (LDS-tiled warp,
+ * derivative and separable window sums).  Flow is double-buffered: shiftsOut
+ * must not alias shiftsIn (tile halos read neighbouring tiles' flow). */
+int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_float2* shiftsOut, int pitchShift,
+                                   const float* refImg, const float* movedImg, int pitchImg, int width, int height,
+                                   int halfWindowSize, float minDet, mfsr_stream_t stream);
+/* E1+E2 (derivatives + structure tensor) in one launch */
+int mfsr_structureTensorFused(const float* img, int imgPitch, mfsr_float3* outImg, int outPitch, int width, int height,
+                              mfsr_stream_t stream);
+/* A2+A3 (+u16 -> float) in one launch through an LDS green tile */
+int mfsr_deBayerFused(const uint16_t* raw, mfsr_float3* outImage, int strideOut, int width, int height,
+                      mfsr_float3 blackPoint, mfsr_float3 scale, mfsr_stream_t stream);
+/* H1 (+fallback resample) + H2 + quantise in one launch */
+int mfsr_finishFused(const mfsr_float3* finalImg, const mfsr_float3* weight, int imgPitch, const mfsr_float3* fallback,
+                     int fbPitch, int fbW, int fbH, float u0, float u1, float v0, float v1, mfsr_float3* outImg,
+                     int outPitch, uint16_t* out16, int width, int height, float threshold, int applyGamma,
+                     float maxOut, mfsr_stream_t stream);
+
+/* ---- burst pipeline (the L3 driver the reference lacks; mirrors the CLI
+ *      contract of finalProject/Project/multi_frame_sr.cpp:122-210) ---------- */
+typedef struct {
+    int32_t width, height;   /* raw / LR frame size (even) */
+    int32_t frames;          /* N */
+    int32_t reference;       /* index of the reference frame */
+    int32_t scale;           /* output scale s (1..8) */
+    int32_t mono;            /* 0: Bayer mosaic per cfa; 1: monochrome (config 1) */
+    int32_t cfa[4];          /* CFA pattern (ignored when mono) */
+    float black[3], white[3]; /* per-channel levels: norm = (raw - black)/white */
+    float maxVal;            /* deBayersSubSample3's maxVal */
+    /* tile tracker */
+    int32_t levels;          /* pyramid levels (1..4), coarsest first */
+    int32_t levelFactor[4];  /* down-sampling factor per level (power of two) */
+    int32_t tileSize[4];
+    int32_t maxShift[4];
+    float minimumThreshold;  /* findMinimum threshold */
+    float sigmaTracking;     /* gaussin_filter_1D sigma of the tracking prefilter (main.cpp:1868) */
+    /* Lucas-Kanade refinement */
+    int32_t lkIterations;
+    int32_t lkHalfWindow;
+    float lkMinDet;
+    /* robustness */
+    float alpha, beta, thresholdM;
+    /* kernel shape */
+    float sigmaTensor;
+    float Dth, Dtr, kDetail, kDenoise, kStretch, kShrink;
+    /* finish */
+    float weightThreshold;
+    int32_t applyGamma;
+    int32_t fused;           /* 1: fused MI355X kernels; 0: one launch per reference kernel */
+    int32_t reserved[7];
+} mfsr_config;
+
+typedef struct mfsr_burst mfsr_burst;
+
+/* fill *cfg with the build's defaults for a width x height x frames burst */
+int mfsr_config_default(mfsr_config* cfg, int width, int height, int frames, int scale, int mono);
+/* device scratch the pipeline needs for cfg (bytes) */
+size_t mfsr_burst_workspace_bytes(const mfsr_config* cfg);
+/* bytes of ONE accumulator plane-set (imgOut or totalWeights): float3, pitch = 12*scale*width */
+size_t mfsr_burst_accumulator_bytes(const mfsr_config* cfg);
+int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void* workspace, size_t workspaceBytes);
+void mfsr_burst_destroy(mfsr_burst* b);
+/* Prepare the reference frame (tracking pyramid, half-res RGB, kernel
+ * parameters, fallback image).  rawRef: dense u16 width x height on device. */
+int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, mfsr_stream_t stream);
+/* Align + robustness + accumulate ONE frame into the caller's accumulators
+ * (float3 HR, pitch 12*scale*width; zeroed by the caller before the first
+ * call).  isReference != 0: identity flow, certainty 1. */
+int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float3* imgOut,
+                         mfsr_float3* totalWeights, mfsr_stream_t stream);
+/* ApplyWeighting (+fallback) + optional gamma; outImg float3 HR (may be NULL),
+ * out16 dense interleaved u16 HR (may be NULL). */
+int mfsr_burst_finish(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights, mfsr_float3* outImg,
+                      uint16_t* out16, mfsr_stream_t stream);
+/* last per-frame flow field (tracking resolution, raw-pixel units) and mask,
+ * for tests: returns device pointers valid until the next add_frame */
+int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2d* mask, mfsr_tex2d* kernelParam,
+                           mfsr_tex2d* tracking);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFSR_H */

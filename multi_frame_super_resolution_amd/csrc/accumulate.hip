@@ -1,0 +1,276 @@
+// accumulate.hip -- the warp+fuse stage: the
+// kernel the headline metric is quoted on.
+// Behavioural spec: reference test_opencv/DeBayerKernels.cu:288-468.
+//
+// Structure (reference structure kept: one launch per frame, accumulators are
+// read-modify-written in HBM, 48 B per HR pixel per frame):
+//   * one thread per HR pixel, 64 x 4 workgroups, rows of 64 consecutive pixels
+//     per wavefront so the four 12-byte accumulator streams (2 loads + 2 stores)
+//     are contiguous 768-byte wave accesses;
+//   * the per-pixel fields (kernel parameters, flow) are fetched with the exact
+//     bilinear arithmetic of the oracle so that roundf(s*flow) -- which decides
+//     the tap geometry -- is bit-identical;
+//   * the 5x5 taps touch only a 3x3 raw neighbourhood and <= 2x2 certainty
+//     texels: raw u16 / mask reads hit L1/L2 (the frame is 16.6 MB at 4K);
+//   * weight exponent: px*px, 2*px*py, py*py are exact small integers, so the
+//     quadratic form costs two rounded adds per tap exactly as in the reference;
+//   * FAST=true evaluates exp(-w/2) as v_exp_f32(w * (-0.5*log2 e)) (<= 2 ulp of
+//     the correctly rounded result, well inside the +-1 LSB output budget);
+//     FAST=false calls the ocml expf for tight parity tests.
+#include "common.hpp"
+
+struct Levels3 {
+    float white[3], black[3];
+};
+
+static inline Levels3 make_levels(mfsr_float3 white, mfsr_float3 black)
+{
+    Levels3 l;
+    l.white[0] = white.x;
+    l.white[1] = white.y;
+    l.white[2] = white.z;
+    l.black[0] = black.x;
+    l.black[1] = black.y;
+    l.black[2] = black.z;
+    return l;
+}
+
+template <bool FAST>
+__device__ __forceinline__ float tap_weight(int px, int py, float kx, float ky, float kz)
+{
+    // DeBayerKernels.cu:335-338 / :427-430
+    float w = (float)(px * px) * kx + (float)(2 * px * py) * kz + (float)(py * py) * ky;
+    if (FAST) {
+        const float t = w * -0.72134752044448170368f;  // -0.5 * log2(e)
+        w = __builtin_amdgcn_exp2f(t);
+    } else {
+        w = expf(-0.5f * w);
+    }
+    if (!finitef(w)) w = (px * py == 0) ? 1.0f : 0.0f;
+    return w;
+}
+
+__device__ __forceinline__ void tap_accumulate(float raw, float w, int color, const float4& cert4, const Levels3& lv,
+                                               pix3& pixel, pix3& totalWeight)
+{
+    // DeBayerKernels.cu:342-370 / :434-462
+    if (color == MFSR_GREEN) {
+        raw = (raw - lv.black[1]) / lv.white[1];
+        float certainty = cert4.y;
+        if (!finitef(certainty)) certainty = 0.0f;
+        pixel.y += raw * w * certainty;
+        totalWeight.y += w * certainty;
+    } else if (color == MFSR_RED) {
+        raw = (raw - lv.black[0]) / lv.white[0];
+        float certainty = cert4.x;
+        if (!finitef(certainty)) certainty = 0.0f;
+        pixel.x += raw * w * certainty;
+        totalWeight.x += w * certainty;
+    } else if (color == MFSR_BLUE) {
+        raw = (raw - lv.black[2]) / lv.white[2];
+        float certainty = cert4.z;
+        if (!finitef(certainty)) certainty = 0.0f;
+        pixel.z += raw * w * certainty;
+        totalWeight.z += w * certainty;
+    }
+}
+
+// ---- G1: accumulateImages (DeBayerKernels.cu:290-376) -------------------------
+__global__ void __launch_bounds__(256)
+    k_accumulateImages(const uint16_t* __restrict__ dataIn, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
+                       const float4* __restrict__ certaintyMask, const pix3* __restrict__ kernelParam,
+                       const float2* __restrict__ shifts, Levels3 lv, int dimX, int dimY, int strideOut, int strideMask,
+                       int strideShift, int cfa)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x < 1 || y < 1 || x >= dimX - 1 || y >= dimY - 1) return;
+    pix3 pixel = row_ptr(imgOut, strideOut, y)[x];
+    pix3 totalWeight = row_ptr(totalWeights, strideOut, y)[x];
+    const pix3 kernel = row_ptr(kernelParam, strideOut, y)[x];  // strideOut: reference quirk (:308)
+    const float2 shift = row_ptr(shifts, strideShift, y)[x];
+    const int sx = f2i(roundf(shift.x));
+    const int sy = f2i(roundf(shift.y));
+#pragma unroll
+    for (int py = -2; py <= 2; py++) {
+        const int ppsy = clampi(y + py + sy, 0, dimY - 1);
+        const int ppy = clampi(y + py, 0, dimY - 1);
+#pragma unroll
+        for (int px = -2; px <= 2; px++) {
+            const int ppsx = clampi(x + px + sx, 0, dimX - 1);
+            const int ppx = clampi(x + px, 0, dimX - 1);
+            const int color = cfa_at(cfa, ppsy, ppsx);
+            const float w = tap_weight<false>(px, py, kernel.x, kernel.y, kernel.z);
+            const float raw = (float)dataIn[(size_t)ppsy * dimX + ppsx];
+            const float4 cert4 = row_ptr(certaintyMask, strideMask, ppy / 2)[ppx / 2];
+            tap_accumulate(raw, w, color, cert4, lv, pixel, totalWeight);
+        }
+    }
+    row_ptr(imgOut, strideOut, y)[x] = pixel;
+    row_ptr(totalWeights, strideOut, y)[x] = totalWeight;
+}
+
+extern "C" int mfsr_accumulateImages(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                                     const mfsr_float4* certaintyMask, const mfsr_float3* kernelParam,
+                                     const mfsr_float2* shifts, mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX,
+                                     int dimY, int strideOut, int strideMask, int strideShift, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(dataIn && imgOut && totalWeights && certaintyMask && kernelParam && shifts);
+    MFSR_REQUIRE(dimX > 2 && dimY > 2);
+    MFSR_REQUIRE((long long)strideOut >= 12LL * dimX && (strideOut & 3) == 0);
+    MFSR_REQUIRE((long long)strideShift >= 8LL * dimX && (strideShift & 7) == 0 && ((uintptr_t)shifts & 7) == 0);
+    MFSR_REQUIRE((long long)strideMask >= 16LL * ((dimX + 1) / 2) && (strideMask & 15) == 0 &&
+                 ((uintptr_t)certaintyMask & 15) == 0);
+    dim3 block(64, 4), grid(mfsr_cdiv(dimX, 64), mfsr_cdiv(dimY, 4));
+    hipLaunchKernelGGL(k_accumulateImages, grid, block, 0, mfsr_s(stream), dataIn, (pix3*)imgOut, (pix3*)totalWeights,
+                       (const float4*)certaintyMask, (const pix3*)kernelParam, (const float2*)shifts,
+                       make_levels(whiteLevel, blackLevel), dimX, dimY, strideOut, strideMask, strideShift,
+                       mfsr_cfa_packed());
+    return mfsr_launch_status("accumulateImages");
+}
+
+// ---- G2: accumulateImagesSuperRes (DeBayerKernels.cu:379-468) and its
+//      full-frame generalisation ------------------------------------------------
+// GEOM_CROP: the reference geometry (x2, output grid dimX x dimY over the central
+//            half of the frame).
+// GEOM_FULL: scale s, output grid (s*dimX) x (s*dimY) over the whole frame.
+enum { GEOM_CROP = 0, GEOM_FULL = 1 };
+
+__device__ __forceinline__ int floordiv_pos(int a, int s)
+{
+    // floor(a / s) for s > 0 and any a
+    int q = a / s;
+    return (a % s < 0) ? q - 1 : q;
+}
+
+template <int GEOM, bool FAST>
+__global__ void __launch_bounds__(256)
+    k_accumulateSuperRes(const uint16_t* __restrict__ dataIn, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
+                         const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 lv,
+                         int dimX, int dimY, int scale, int strideOut, int strideMask, int cfa)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int outW = (GEOM == GEOM_CROP) ? dimX : dimX * scale;
+    const int outH = (GEOM == GEOM_CROP) ? dimY : dimY * scale;
+    if (x < 1 || y < 1 || x >= outW - 1 || y >= outH - 1) return;
+
+    pix3 pixel = row_ptr(imgOut, strideOut, y)[x];
+    pix3 totalWeight = row_ptr(totalWeights, strideOut, y)[x];
+
+    float posX, posY, fscale;
+    if (GEOM == GEOM_CROP) {
+        posX = ((float)x + 0.5f + (float)(dimX / 2)) / 2.0f / (float)dimX;  // :398
+        posY = ((float)y + 0.5f + (float)(dimY / 2)) / 2.0f / (float)dimY;
+        fscale = 2.0f;
+    } else {
+        posX = ((float)x + 0.5f) / (float)outW;
+        posY = ((float)y + 0.5f) / (float)outH;
+        fscale = (float)scale;
+    }
+    const float4 kernel = tex4<ADDR_CLAMP>(kernelParam, posX, posY);
+    const float2 shift = tex2<ADDR_CLAMP>(shifts, posX, posY);
+    const int sx = f2i(roundf(shift.x * fscale));  // :403-406
+    const int sy = f2i(roundf(shift.y * fscale));
+
+    int ppsxA[5], ppxA[5];
+#pragma unroll
+    for (int px = -2; px <= 2; px++) {
+        if (GEOM == GEOM_CROP) {
+            ppsxA[px + 2] = clampi((x + px + sx + dimX / 2) / 2, dimX / 4, dimX / 2 - 1 + dimX / 4);  // :419
+            ppxA[px + 2] = clampi((x + px + dimX / 2) / 2, dimX / 4, dimX / 2 - 1 + dimX / 4);        // :422
+        } else {
+            ppsxA[px + 2] = clampi(floordiv_pos(x + px + sx, scale), 0, dimX - 1);
+            ppxA[px + 2] = clampi(floordiv_pos(x + px, scale), 0, dimX - 1);
+        }
+    }
+#pragma unroll
+    for (int py = -2; py <= 2; py++) {
+        int ppsy, ppy;
+        if (GEOM == GEOM_CROP) {
+            ppsy = clampi((y + py + sy + dimY / 2) / 2, dimY / 4, dimY / 2 - 1 + dimY / 4);
+            ppy = clampi((y + py + dimY / 2) / 2, dimY / 4, dimY / 2 - 1 + dimY / 4);
+        } else {
+            ppsy = clampi(floordiv_pos(y + py + sy, scale), 0, dimY - 1);
+            ppy = clampi(floordiv_pos(y + py, scale), 0, dimY - 1);
+        }
+        const uint16_t* rawRow = dataIn + (size_t)ppsy * dimX;
+        const float4* maskRow = row_ptr(certaintyMask, strideMask, ppy / 2);
+#pragma unroll
+        for (int px = -2; px <= 2; px++) {
+            const int ppsx = ppsxA[px + 2];
+            const int color = cfa_at(cfa, ppsy, ppsx);
+            const float w = tap_weight<FAST>(px, py, kernel.x, kernel.y, kernel.z);
+            const float raw = (float)rawRow[ppsx];
+            const float4 cert4 = maskRow[ppxA[px + 2] / 2];
+            tap_accumulate(raw, w, color, cert4, lv, pixel, totalWeight);
+        }
+    }
+    row_ptr(imgOut, strideOut, y)[x] = pixel;
+    row_ptr(totalWeights, strideOut, y)[x] = totalWeight;
+}
+
+static int g_accumulate_fast = 1;
+// test hook: 0 selects the ocml expf path (tight parity), 1 the v_exp_f32 path
+extern "C" int mfsr_set_accumulate_fast_exp(int enable)
+{
+    g_accumulate_fast = enable ? 1 : 0;
+    return MFSR_OK;
+}
+
+static int check_superres_args(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                               const mfsr_float4* certaintyMask, const mfsr_tex2d& kernelParam, const mfsr_tex2d& shifts,
+                               int dimX, int dimY, int outW, int strideOut, int strideMask)
+{
+    MFSR_REQUIRE(dataIn && imgOut && totalWeights && certaintyMask);
+    MFSR_REQUIRE(dimX >= 8 && dimY >= 8);
+    MFSR_REQUIRE(mfsr_tex_ok(kernelParam, 16) && ((uintptr_t)kernelParam.ptr & 15) == 0 && (kernelParam.pitch & 15) == 0);
+    MFSR_REQUIRE(mfsr_tex_ok(shifts, 8) && ((uintptr_t)shifts.ptr & 7) == 0 && (shifts.pitch & 7) == 0);
+    MFSR_REQUIRE((long long)strideOut >= 12LL * outW && (strideOut & 3) == 0);
+    MFSR_REQUIRE((long long)strideMask >= 16LL * ((dimX + 1) / 2) && (strideMask & 15) == 0 &&
+                 ((uintptr_t)certaintyMask & 15) == 0);
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_accumulateImagesSuperRes(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                                             const mfsr_float4* certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts,
+                                             mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY,
+                                             int strideOut, int strideMask, mfsr_stream_t stream)
+{
+    int rc = check_superres_args(dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, dimX, dimY, dimX,
+                                 strideOut, strideMask);
+    if (rc) return rc;
+    dim3 block(64, 4), grid(mfsr_cdiv(dimX, 64), mfsr_cdiv(dimY, 4));
+    const Levels3 lv = make_levels(whiteLevel, blackLevel);
+    if (g_accumulate_fast)
+        hipLaunchKernelGGL((k_accumulateSuperRes<GEOM_CROP, true>), grid, block, 0, mfsr_s(stream), dataIn, (pix3*)imgOut,
+                           (pix3*)totalWeights, (const float4*)certaintyMask, kernelParam, shifts, lv, dimX, dimY, 2,
+                           strideOut, strideMask, mfsr_cfa_packed());
+    else
+        hipLaunchKernelGGL((k_accumulateSuperRes<GEOM_CROP, false>), grid, block, 0, mfsr_s(stream), dataIn,
+                           (pix3*)imgOut, (pix3*)totalWeights, (const float4*)certaintyMask, kernelParam, shifts, lv, dimX,
+                           dimY, 2, strideOut, strideMask, mfsr_cfa_packed());
+    return mfsr_launch_status("accumulateImagesSuperRes");
+}
+
+extern "C" int mfsr_accumulateSuperResFull(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                                           const mfsr_float4* certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts,
+                                           mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int scale,
+                                           int strideOut, int strideMask, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(scale >= 1 && scale <= 8);
+    int rc = check_superres_args(dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, dimX, dimY,
+                                 dimX * scale, strideOut, strideMask);
+    if (rc) return rc;
+    dim3 block(64, 4), grid(mfsr_cdiv((long long)dimX * scale, 64), mfsr_cdiv((long long)dimY * scale, 4));
+    const Levels3 lv = make_levels(whiteLevel, blackLevel);
+    if (g_accumulate_fast)
+        hipLaunchKernelGGL((k_accumulateSuperRes<GEOM_FULL, true>), grid, block, 0, mfsr_s(stream), dataIn, (pix3*)imgOut,
+                           (pix3*)totalWeights, (const float4*)certaintyMask, kernelParam, shifts, lv, dimX, dimY, scale,
+                           strideOut, strideMask, mfsr_cfa_packed());
+    else
+        hipLaunchKernelGGL((k_accumulateSuperRes<GEOM_FULL, false>), grid, block, 0, mfsr_s(stream), dataIn,
+                           (pix3*)imgOut, (pix3*)totalWeights, (const float4*)certaintyMask, kernelParam, shifts, lv, dimX,
+                           dimY, scale, strideOut, strideMask, mfsr_cfa_packed());
+    return mfsr_launch_status("accumulateSuperResFull");
+}

@@ -1,0 +1,542 @@
+// pipeline.cpp -- burst driver: N raw frames in -> one x-s frame out.
+//
+// This is the L3 layer the reference lacks for its ImageStackAlignator kernels
+// (the order below is reconstructed from the kernels'
+// data dependencies; the reference's only working burst driver,
+// finalProject/Project/multi_frame_sr.cpp:146-209, drives third-party OpenCV
+// code).  Stage letters follow SURVEY.md section 3.3:
+//
+//   set_reference : A1 half-res RGB, tracking pyramid (gray -> gaussin_filter_1D
+//                   prefilter -> 2x box levels), E structure tensor -> smooth ->
+//                   ComputeKernelParam, A2+A3 debayered fallback image
+//   add_frame     : A1, tracking pyramid, B tile tracking coarse -> fine,
+//                   D CreateFlowFieldFromTiles + K Lucas-Kanade iterations,
+//                   F ComputeRobustnessMask, G accumulate onto the HR grid
+//   finish        : H ApplyWeighting (+fallback) + GammasRGB (+quantise)
+//
+// The joint shift minimiser (C) is the identity when only (reference, k) pairs
+// are measured, which is the per-frame streaming / frame-sharded mode this
+// driver implements; it is exposed separately (mfsr_minimizeShifts).
+//
+// Everything runs on the caller's stream out of the caller's workspace: no
+// allocation, no synchronisation, so a whole add_frame chain can be captured in
+// a hipGraph.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMaxLevels = 4;
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Img {
+    void* ptr = nullptr;
+    int pitch = 0;
+    int w = 0, h = 0;
+};
+
+struct Layout {
+    // geometry
+    int W, H, hw, hh, tw, th, hrW, hrH;
+    int flowScale;
+    int lw[kMaxLevels], lh[kMaxLevels];      // level image dims
+    int tcx[kMaxLevels], tcy[kMaxLevels];    // tile counts per level
+    int maxFactor;
+    // buffers
+    Img refHalf, movHalf;                    // float3, half res
+    Img refPyr[8], movPyr[8];                // float, factor 1,2,4,.. (index = log2 factor)
+    Img kparam4;                             // float4, tracking res
+    Img tensor, tensorTmp, tensorSm;         // float3, tracking res
+    Img fallback;                            // float3, W x H
+    Img tmpA, tmpB;                          // float, tracking res
+    Img flowA, flowB;                        // float2, tracking res
+    Img mask;                                // float4, half res
+    Img shifts[kMaxLevels], pre[kMaxLevels]; // float2, tile grids
+    // unfused path scratch
+    Img warped, Ix, Iy, It, rawf;
+    float *refTiles, *movTiles, *cc, *boxX, *boxY, *sqsum, *dist;
+    size_t total;
+};
+
+struct Bump {
+    char* base;
+    size_t off;
+    void* take(size_t bytes)
+    {
+        off = align_up(off, 256);
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+    Img image(int w, int h, int elemBytes)
+    {
+        Img im;
+        im.w = w;
+        im.h = h;
+        im.pitch = (int)align_up((size_t)w * elemBytes, 64);
+        im.ptr = take((size_t)im.pitch * h);
+        return im;
+    }
+};
+
+int ilog2(int v)
+{
+    int l = 0;
+    while ((1 << l) < v) l++;
+    return l;
+}
+
+int validate(const mfsr_config* c)
+{
+    MFSR_REQUIRE(c != nullptr);
+    MFSR_REQUIRE(c->width >= 64 && c->height >= 64 && (c->width % 4) == 0 && (c->height % 4) == 0);
+    MFSR_REQUIRE(c->frames >= 1 && c->reference >= 0 && c->reference < c->frames);
+    MFSR_REQUIRE(c->scale >= 1 && c->scale <= 8);
+    MFSR_REQUIRE(c->levels >= 1 && c->levels <= kMaxLevels);
+    MFSR_REQUIRE(c->levelFactor[c->levels - 1] == 1);
+    for (int l = 0; l < c->levels; l++) {
+        const int f = c->levelFactor[l];
+        MFSR_REQUIRE(f >= 1 && f <= 128 && (f & (f - 1)) == 0);
+        if (l > 0) MFSR_REQUIRE(c->levelFactor[l] < c->levelFactor[l - 1]);
+        MFSR_REQUIRE(c->tileSize[l] >= 4 && c->tileSize[l] <= 128 && c->maxShift[l] >= 1 && c->maxShift[l] <= 15);
+        MFSR_REQUIRE(c->tileSize[l] > 2 * c->maxShift[l]);
+    }
+    MFSR_REQUIRE(c->lkIterations >= 0 && c->lkHalfWindow >= 0 && c->lkHalfWindow <= 15);
+    MFSR_REQUIRE(c->maxVal > 0);
+    return MFSR_OK;
+}
+
+void make_layout(const mfsr_config* c, char* base, Layout* L)
+{
+    memset((void*)L, 0, sizeof(*L));
+    Bump b{base, 0};
+    L->W = c->width;
+    L->H = c->height;
+    L->hw = c->width / 2;
+    L->hh = c->height / 2;
+    L->tw = c->mono ? L->W : L->hw;
+    L->th = c->mono ? L->H : L->hh;
+    L->flowScale = c->mono ? 1 : 2;
+    L->hrW = c->width * c->scale;
+    L->hrH = c->height * c->scale;
+    L->maxFactor = c->levelFactor[0];
+    const int nl = ilog2(L->maxFactor) + 1;
+
+    L->refHalf = b.image(L->hw, L->hh, 12);
+    L->movHalf = b.image(L->hw, L->hh, 12);
+    for (int i = 0; i < nl; i++) {
+        L->refPyr[i] = b.image(L->tw >> i, L->th >> i, 4);
+        L->movPyr[i] = b.image(L->tw >> i, L->th >> i, 4);
+    }
+    L->kparam4 = b.image(L->tw, L->th, 16);
+    L->tensor = b.image(L->tw, L->th, 12);
+    L->tensorTmp = b.image(L->tw, L->th, 12);
+    L->tensorSm = b.image(L->tw, L->th, 12);
+    L->fallback = b.image(L->W, L->H, 12);
+    L->tmpA = b.image(L->tw, L->th, 4);
+    L->tmpB = b.image(L->tw, L->th, 4);
+    L->flowA = b.image(L->tw, L->th, 8);
+    L->flowB = b.image(L->tw, L->th, 8);
+    L->mask = b.image(L->hw, L->hh, 16);
+    size_t maxTileFloats = 0, maxTiles = 0, maxDist = 0;
+    for (int l = 0; l < c->levels; l++) {
+        const int f = c->levelFactor[l];
+        L->lw[l] = L->tw / f;
+        L->lh[l] = L->th / f;
+        L->tcx[l] = L->lw[l] / c->tileSize[l] > 0 ? L->lw[l] / c->tileSize[l] : 1;
+        L->tcy[l] = L->lh[l] / c->tileSize[l] > 0 ? L->lh[l] / c->tileSize[l] : 1;
+        L->shifts[l] = b.image(L->tcx[l], L->tcy[l], 8);
+        L->pre[l] = b.image(L->tcx[l], L->tcy[l], 8);
+        const size_t tiles = (size_t)L->tcx[l] * L->tcy[l];
+        const size_t Lt = (size_t)c->tileSize[l] + 2 * c->maxShift[l];
+        const size_t R = 2 * (size_t)c->maxShift[l] + 1;
+        if (tiles * Lt * Lt > maxTileFloats) maxTileFloats = tiles * Lt * Lt;
+        if (tiles > maxTiles) maxTiles = tiles;
+        if (tiles * R * R > maxDist) maxDist = tiles * R * R;
+    }
+    if (!c->fused) {
+        L->warped = b.image(L->tw, L->th, 4);
+        L->Ix = b.image(L->tw, L->th, 4);
+        L->Iy = b.image(L->tw, L->th, 4);
+        L->It = b.image(L->tw, L->th, 4);
+        L->rawf = b.image(L->W, L->H, 4);
+        L->refTiles = (float*)b.take(maxTileFloats * 4);
+        L->movTiles = (float*)b.take(maxTileFloats * 4);
+        L->cc = (float*)b.take(maxTileFloats * 4);
+        L->boxX = (float*)b.take(maxTileFloats * 4);
+        L->boxY = (float*)b.take(maxTileFloats * 4);
+        L->sqsum = (float*)b.take(maxTiles * 4);
+        L->dist = (float*)b.take(maxDist * 4);
+    }
+    L->total = align_up(b.off, 256);
+}
+
+mfsr_tex2d as_tex(const Img& im)
+{
+    mfsr_tex2d t;
+    t.ptr = im.ptr;
+    t.pitch = im.pitch;
+    t.width = im.w;
+    t.height = im.h;
+    return t;
+}
+
+}  // namespace
+
+struct mfsr_burst {
+    mfsr_config cfg;
+    Layout L;
+    float taps[99];
+    int ntaps;
+    float tensorTaps[99];
+    int ntensorTaps;
+    Img* flowCur;  // flow of the last add_frame (raw-pixel units)
+    bool haveRef;
+};
+
+#define TRY(expr)                  \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != MFSR_OK) return rc_; \
+    } while (0)
+
+extern "C" int mfsr_config_default(mfsr_config* cfg, int width, int height, int frames, int scale, int mono)
+{
+    MFSR_REQUIRE(cfg != nullptr);
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->width = width;
+    cfg->height = height;
+    cfg->frames = frames;
+    cfg->reference = 0;
+    cfg->scale = scale;
+    cfg->mono = mono;
+    if (mono) {
+        cfg->cfa[0] = cfg->cfa[1] = cfg->cfa[2] = cfg->cfa[3] = MFSR_GREEN;
+    } else {
+        cfg->cfa[0] = MFSR_RED;
+        cfg->cfa[1] = MFSR_GREEN;
+        cfg->cfa[2] = MFSR_GREEN;
+        cfg->cfa[3] = MFSR_BLUE;
+    }
+    // 12-bit sensor, black level 256 (SURVEY.md section 8d synthetic-input recipe)
+    for (int i = 0; i < 3; i++) {
+        cfg->black[i] = 256.0f;
+        cfg->white[i] = 4095.0f - 256.0f;
+    }
+    cfg->maxVal = 4095.0f;
+    cfg->levels = 2;
+    cfg->levelFactor[0] = 2;
+    cfg->levelFactor[1] = 1;
+    cfg->tileSize[0] = 32;
+    cfg->tileSize[1] = 32;
+    cfg->maxShift[0] = 4;
+    cfg->maxShift[1] = 4;
+    cfg->minimumThreshold = 0.0f;
+    cfg->sigmaTracking = 0.5f;  // SigmaDebayerTracking, test_opencv/main.cpp:1868
+    cfg->lkIterations = 3;
+    cfg->lkHalfWindow = 3;
+    cfg->lkMinDet = 1e-4f;
+    cfg->alpha = 1e-4f;
+    cfg->beta = 1e-6f;
+    cfg->thresholdM = 1.0f;
+    cfg->sigmaTensor = 1.0f;
+    cfg->Dth = 0.005f;
+    cfg->Dtr = 0.05f;
+    cfg->kDetail = 0.3f;
+    cfg->kDenoise = 2.0f;
+    cfg->kStretch = 2.0f;
+    cfg->kShrink = 2.0f;
+    cfg->weightThreshold = 1e-3f;
+    cfg->applyGamma = 0;
+    cfg->fused = 1;
+    return MFSR_OK;
+}
+
+extern "C" size_t mfsr_burst_workspace_bytes(const mfsr_config* cfg)
+{
+    if (validate(cfg) != MFSR_OK) return 0;
+    Layout L;
+    make_layout(cfg, nullptr, &L);
+    return L.total;
+}
+
+extern "C" size_t mfsr_burst_accumulator_bytes(const mfsr_config* cfg)
+{
+    if (!cfg || cfg->width <= 0 || cfg->height <= 0 || cfg->scale <= 0) return 0;
+    return (size_t)12 * cfg->scale * cfg->width * (size_t)cfg->scale * cfg->height;
+}
+
+extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void* workspace, size_t workspaceBytes)
+{
+    MFSR_REQUIRE(out != nullptr && workspace != nullptr);
+    TRY(validate(cfg));
+    if (mfsr_device_count() <= 0) {
+        fprintf(stderr, "mfsr: no HIP device available (there is no CPU fallback)\n");
+        return MFSR_E_NODEVICE;
+    }
+    MFSR_REQUIRE(((uintptr_t)workspace & 255) == 0);
+    mfsr_burst* b = new (std::nothrow) mfsr_burst;
+    MFSR_REQUIRE(b != nullptr);
+    b->cfg = *cfg;
+    make_layout(cfg, (char*)workspace, &b->L);
+    if (b->L.total > workspaceBytes) {
+        fprintf(stderr, "mfsr: workspace too small: need %zu bytes, got %zu\n", b->L.total, workspaceBytes);
+        delete b;
+        return MFSR_E_WORKSPACE;
+    }
+    b->ntaps = mfsr_gaussin_filter_1D(cfg->sigmaTracking, b->taps);
+    b->ntensorTaps = mfsr_gaussin_filter_1D(cfg->sigmaTensor, b->tensorTaps);
+    b->flowCur = &b->L.flowA;
+    b->haveRef = false;
+    *out = b;
+    return MFSR_OK;
+}
+
+extern "C" void mfsr_burst_destroy(mfsr_burst* b) { delete b; }
+
+// A1 + tracking pyramid for one frame (shared by reference and moved frames)
+static int prepare_frame(mfsr_burst* b, const uint16_t* raw, Img& half, Img* pyr, mfsr_stream_t stream)
+{
+    const mfsr_config& c = b->cfg;
+    Layout& L = b->L;
+    TRY(mfsr_set_cfa_pattern(c.cfa));
+    const float maxValEff = c.mono ? 2.0f * c.maxVal : c.maxVal;  // mono: 4 "greens" x 0.5 -> mean of the quad
+    TRY(mfsr_deBayersSubSample3(raw, (mfsr_float3*)half.ptr, maxValEff, L.hw, L.hh, half.pitch, stream));
+    if (c.mono)
+        TRY(mfsr_u16ToFloat(raw, (float*)L.tmpA.ptr, L.tmpA.pitch, L.W, L.H, 1.0f / c.maxVal, stream));
+    else
+        TRY(mfsr_rgbToGray((const mfsr_float3*)half.ptr, half.pitch, (float*)L.tmpA.ptr, L.tmpA.pitch, L.tw, L.th, stream));
+    TRY(mfsr_separableFilter((const float*)L.tmpA.ptr, L.tmpA.pitch, (float*)L.tmpB.ptr, (float*)pyr[0].ptr, pyr[0].pitch,
+                             L.tw, L.th, 1, b->taps, b->ntaps, stream));
+    const int nl = ilog2(L.maxFactor) + 1;
+    for (int i = 1; i < nl; i++)
+        TRY(mfsr_downsample2x((const float*)pyr[i - 1].ptr, pyr[i - 1].pitch, (float*)pyr[i].ptr, pyr[i].pitch, pyr[i].w,
+                              pyr[i].h, stream));
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && rawRef);
+    const mfsr_config& c = b->cfg;
+    Layout& L = b->L;
+    TRY(prepare_frame(b, rawRef, L.refHalf, L.refPyr, stream));
+
+    // E: kernel shape field from the reference tracking image
+    if (c.fused) {
+        TRY(mfsr_structureTensorFused((const float*)L.refPyr[0].ptr, L.refPyr[0].pitch, (mfsr_float3*)L.tensor.ptr,
+                                      L.tensor.pitch, L.tw, L.th, stream));
+    } else {
+        TRY(mfsr_ComputeDerivatives2Kernel(L.tw, L.th, L.Ix.pitch, (float*)L.Ix.ptr, (float*)L.Iy.ptr, as_tex(L.refPyr[0]),
+                                           stream));
+        TRY(mfsr_ComputeStructureTensor((const float*)L.Ix.ptr, (const float*)L.Iy.ptr, (mfsr_float3*)L.tensor.ptr, L.tw,
+                                        L.th, L.Ix.pitch, L.tensor.pitch, stream));
+    }
+    TRY(mfsr_separableFilter((const float*)L.tensor.ptr, L.tensor.pitch, (float*)L.tensorTmp.ptr, (float*)L.tensorSm.ptr,
+                             L.tensorSm.pitch, L.tw, L.th, 3, b->tensorTaps, b->ntensorTaps, stream));
+    TRY(mfsr_ComputeKernelParam((mfsr_float3*)L.tensorSm.ptr, L.tw, L.th, L.tensorSm.pitch, c.Dth, c.Dtr, c.kDetail,
+                                c.kDenoise, c.kStretch, c.kShrink, stream));
+    TRY(mfsr_float3ToFloat4((const mfsr_float3*)L.tensorSm.ptr, L.tensorSm.pitch, (mfsr_float4*)L.kparam4.ptr,
+                            L.kparam4.pitch, L.tw, L.th, stream));
+
+    // A2 + A3: debayered reference = fallback image of ApplyWeighting
+    const mfsr_float3 bp = {c.black[0], c.black[1], c.black[2]};
+    const mfsr_float3 sc = {1.0f / c.white[0], 1.0f / c.white[1], 1.0f / c.white[2]};
+    MFSR_HIP_TRY(hipMemsetAsync(L.fallback.ptr, 0, (size_t)L.fallback.pitch * L.fallback.h, mfsr_s(stream)));
+    if (c.fused) {
+        TRY(mfsr_deBayerFused(rawRef, (mfsr_float3*)L.fallback.ptr, L.fallback.pitch, L.W, L.H, bp, sc, stream));
+    } else {
+        TRY(mfsr_u16ToFloat(rawRef, (float*)L.rawf.ptr, L.rawf.pitch, L.W, L.H, 1.0f, stream));
+        TRY(mfsr_deBayerGreenKernel(L.W, L.H, (const float*)L.rawf.ptr, L.rawf.pitch, (mfsr_float3*)L.fallback.ptr,
+                                    L.fallback.pitch, bp, sc, stream));
+        TRY(mfsr_deBayerRedBlueKernel(L.W, L.H, (const float*)L.rawf.ptr, L.rawf.pitch, (mfsr_float3*)L.fallback.ptr,
+                                      L.fallback.pitch, bp, sc, stream));
+    }
+    b->haveRef = true;
+    return MFSR_OK;
+}
+
+// B: coarse -> fine tile tracking of the moved pyramid against the reference
+static int track_tiles(mfsr_burst* b, mfsr_stream_t stream)
+{
+    const mfsr_config& c = b->cfg;
+    Layout& L = b->L;
+    const mfsr_float2 zero2 = {0.0f, 0.0f};
+    for (int l = 0; l < c.levels; l++) {
+        const int pi = ilog2(c.levelFactor[l]);
+        const Img& ref = L.refPyr[pi];
+        const Img& mov = L.movPyr[pi];
+        const int T = c.tileSize[l], S = c.maxShift[l];
+        const int tiles = L.tcx[l] * L.tcy[l];
+        const mfsr_float2* pre = nullptr;
+        if (l > 0) {
+            TRY(mfsr_UpSampleShifts((const mfsr_float2*)L.shifts[l - 1].ptr, (mfsr_float2*)L.pre[l].ptr,
+                                    L.shifts[l - 1].pitch, L.pre[l].pitch, c.levelFactor[l - 1], c.levelFactor[l],
+                                    L.tcx[l - 1], L.tcy[l - 1], L.tcx[l], L.tcy[l], c.tileSize[l - 1], T, stream));
+            pre = (const mfsr_float2*)L.pre[l].ptr;
+        }
+        if (c.fused) {
+            TRY(mfsr_trackTilesFused((const float*)ref.ptr, (const float*)mov.ptr, pre, L.pre[l].pitch,
+                                     (mfsr_float2*)L.shifts[l].ptr, L.shifts[l].pitch, ref.w, ref.h, ref.pitch, S, T,
+                                     L.tcx[l], L.tcy[l], c.minimumThreshold, stream));
+        } else {
+            if (!pre) {
+                MFSR_HIP_TRY(hipMemsetAsync(L.pre[l].ptr, 0, (size_t)L.pre[l].pitch * L.pre[l].h, mfsr_s(stream)));
+                pre = (const mfsr_float2*)L.pre[l].ptr;
+            }
+            TRY(mfsr_convertToTilesOverlapBorder((const float*)ref.ptr, L.refTiles, ref.w, ref.h, ref.pitch, S, T, L.tcx[l],
+                                                 L.tcy[l], zero2, 0.0f, stream));
+            TRY(mfsr_convertToTilesOverlapPreShift((const float*)mov.ptr, L.movTiles, pre, L.pre[l].pitch, mov.w, mov.h,
+                                                   mov.pitch, S, T, L.tcx[l], L.tcy[l], zero2, 0.0f, stream));
+            TRY(mfsr_crossCorrelateTiles(L.refTiles, L.movTiles, L.cc, S, T, tiles, stream));
+            TRY(mfsr_squaredSum(L.refTiles, L.sqsum, S, T, tiles, stream));
+            TRY(mfsr_boxFilterWithBorderX(L.movTiles, L.boxX, S, T, tiles, stream));
+            TRY(mfsr_boxFilterWithBorderY(L.boxX, L.boxY, S, T, tiles, stream));
+            TRY(mfsr_normalizedCC(L.cc, L.sqsum, L.boxY, L.dist, S, T, tiles, stream));
+            TRY(mfsr_findMinimum(L.dist, (mfsr_float2*)L.shifts[l].ptr, L.shifts[l].pitch, S, tiles, L.tcx[l],
+                                 c.minimumThreshold, stream));
+            TRY(mfsr_addRoundedPreShift(pre, L.pre[l].pitch, (mfsr_float2*)L.shifts[l].ptr, L.shifts[l].pitch, L.tcx[l],
+                                        L.tcy[l], stream));
+        }
+    }
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float3* imgOut,
+                                    mfsr_float3* totalWeights, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && raw && imgOut && totalWeights);
+    MFSR_REQUIRE(b->haveRef);
+    const mfsr_config& c = b->cfg;
+    Layout& L = b->L;
+    const mfsr_float3 white = {c.white[0], c.white[1], c.white[2]};
+    const mfsr_float3 black = {c.black[0], c.black[1], c.black[2]};
+    const int strideOut = 12 * L.hrW;
+    TRY(mfsr_set_cfa_pattern(c.cfa));
+
+    Img* flow = &L.flowA;
+    if (isReference) {
+        // identity flow, certainty 1
+        MFSR_HIP_TRY(hipMemsetAsync(L.flowA.ptr, 0, (size_t)L.flowA.pitch * L.flowA.h, mfsr_s(stream)));
+        TRY(mfsr_fill_f32((float*)L.mask.ptr, (size_t)L.mask.pitch / 4 * L.mask.h, 1.0f, stream));
+    } else {
+        TRY(prepare_frame(b, raw, L.movHalf, L.movPyr, stream));
+        TRY(track_tiles(b, stream));
+        const int last = c.levels - 1;
+        const mfsr_float2 zero2 = {0.0f, 0.0f};
+        TRY(mfsr_CreateFlowFieldFromTiles((mfsr_float2*)L.flowA.ptr, as_tex(L.shifts[last]), c.tileSize[last], L.tcx[last],
+                                          L.tcy[last], L.tw, L.th, L.flowA.pitch, zero2, 0.0f, stream));
+        Img* other = &L.flowB;
+        for (int it = 0; it < c.lkIterations; it++) {
+            if (c.fused) {
+                TRY(mfsr_lucasKanadeIterationFused((const mfsr_float2*)flow->ptr, (mfsr_float2*)other->ptr, flow->pitch,
+                                                   (const float*)L.refPyr[0].ptr, (const float*)L.movPyr[0].ptr,
+                                                   L.refPyr[0].pitch, L.tw, L.th, c.lkHalfWindow, c.lkMinDet, stream));
+                Img* t = flow;
+                flow = other;
+                other = t;
+            } else {
+                TRY(mfsr_WarpingKernel(L.tw, L.th, L.warped.pitch, as_tex(*flow), (float*)L.warped.ptr, as_tex(L.movPyr[0]),
+                                       stream));
+                TRY(mfsr_ComputeDerivativesKernel(L.tw, L.th, L.Ix.pitch, (float*)L.Ix.ptr, (float*)L.Iy.ptr,
+                                                  (float*)L.It.ptr, as_tex(L.refPyr[0]), as_tex(L.warped), stream));
+                TRY(mfsr_lucasKanadeOptim((mfsr_float2*)flow->ptr, (const float*)L.Ix.ptr, (const float*)L.Iy.ptr,
+                                          (const float*)L.It.ptr, flow->pitch, L.Ix.pitch, L.tw, L.th, c.lkHalfWindow,
+                                          c.lkMinDet, stream));
+            }
+        }
+        if (L.flowScale != 1)
+            TRY(mfsr_scaleFlow((mfsr_float2*)flow->ptr, flow->pitch, L.tw, L.th, (float)L.flowScale, stream));
+        // F: robustness mask (1-px ring is never written by the kernel -> pre-zero)
+        MFSR_HIP_TRY(hipMemsetAsync(L.mask.ptr, 0, (size_t)L.mask.pitch * L.mask.h, mfsr_s(stream)));
+        TRY(mfsr_ComputeRobustnessMask((const mfsr_float3*)L.refHalf.ptr, (const mfsr_float3*)L.movHalf.ptr,
+                                       (mfsr_float4*)L.mask.ptr, as_tex(*flow), L.hw, L.hh, L.refHalf.pitch, L.mask.pitch,
+                                       c.alpha, c.beta, c.thresholdM, stream));
+    }
+    b->flowCur = flow;
+    // G: accumulate onto the HR grid
+    TRY(mfsr_accumulateSuperResFull(raw, imgOut, totalWeights, (const mfsr_float4*)L.mask.ptr, as_tex(L.kparam4),
+                                    as_tex(*flow), white, black, L.W, L.H, c.scale, strideOut, L.mask.pitch, stream));
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_burst_finish(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights,
+                                 mfsr_float3* outImg, uint16_t* out16, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && imgOut && totalWeights && (outImg || out16));
+    MFSR_REQUIRE(b->haveRef);
+    const mfsr_config& c = b->cfg;
+    Layout& L = b->L;
+    const int pitch = 12 * L.hrW;
+    if (c.fused) {
+        return mfsr_finishFused(imgOut, totalWeights, pitch, (const mfsr_float3*)L.fallback.ptr, L.fallback.pitch, L.W, L.H,
+                                0.0f, 1.0f, 0.0f, 1.0f, outImg, pitch, out16, L.hrW, L.hrH, c.weightThreshold,
+                                c.applyGamma, 65535.0f, stream);
+    }
+    MFSR_REQUIRE(outImg != nullptr);  // the unfused chain needs the float image as its in/out buffer
+    TRY(mfsr_resampleFloat3((const mfsr_float3*)L.fallback.ptr, L.fallback.pitch, L.W, L.H, outImg, pitch, L.hrW, L.hrH,
+                            0.0f, 1.0f, 0.0f, 1.0f, stream));
+    TRY(mfsr_ApplyWeighting(outImg, imgOut, totalWeights, L.hrW, L.hrH, pitch, c.weightThreshold, stream));
+    if (c.applyGamma) TRY(mfsr_GammasRGB(outImg, L.hrW, L.hrH, pitch, stream));
+    if (out16) TRY(mfsr_quantize(outImg, pitch, out16, nullptr, L.hrW, L.hrH, 65535.0f, stream));
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2d* mask, mfsr_tex2d* kernelParam,
+                                      mfsr_tex2d* tracking)
+{
+    MFSR_REQUIRE(b != nullptr);
+    if (flow) *flow = as_tex(*b->flowCur);
+    if (mask) *mask = as_tex(b->L.mask);
+    if (kernelParam) *kernelParam = as_tex(b->L.kparam4);
+    if (tracking) *tracking = as_tex(b->L.refPyr[0]);
+    return MFSR_OK;
+}
+
+// ---- C: joint shift minimiser driver (solve -> checkForOutliers until every tile
+//      reports -1).  status/inversionInfo are device arrays of tileCount ints; the
+//      loop is bounded by shiftCount rounds and polls the device once per round. ----
+extern "C" int mfsr_minimizeShifts(float* shiftMatrix, mfsr_float2* measuredShifts, mfsr_float2* shiftsOneToOne,
+                                   float* optimShiftsT, int* status, int* inversionInfo, int tileCount, int imageCount,
+                                   int shiftCount, int* roundsOut, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(shiftMatrix && measuredShifts && shiftsOneToOne && optimShiftsT && status && inversionInfo);
+    MFSR_REQUIRE(tileCount > 0 && imageCount > 1 && shiftCount > 0);
+    MFSR_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int) * (size_t)tileCount, mfsr_s(stream)));
+    int* hstatus = new (std::nothrow) int[tileCount];
+    MFSR_REQUIRE(hstatus != nullptr);
+    int rounds = 0, rc = MFSR_OK;
+    for (; rounds < shiftCount + 1; rounds++) {
+        rc = mfsr_solveShiftsBatched(shiftMatrix, measuredShifts, shiftsOneToOne, optimShiftsT, inversionInfo, tileCount,
+                                     imageCount, shiftCount, stream);
+        if (rc) break;
+        rc = mfsr_checkForOutliers(measuredShifts, optimShiftsT, shiftMatrix, status, inversionInfo, tileCount, imageCount,
+                                   shiftCount, stream);
+        if (rc) break;
+        hipError_t e = hipMemcpyAsync(hstatus, status, sizeof(int) * (size_t)tileCount, hipMemcpyDeviceToHost, mfsr_s(stream));
+        if (e == hipSuccess) e = hipStreamSynchronize(mfsr_s(stream));
+        if (e != hipSuccess) {
+            rc = (int)e;
+            break;
+        }
+        bool done = true;
+        for (int i = 0; i < tileCount; i++)
+            if (hstatus[i] >= 0) {
+                done = false;
+                break;
+            }
+        if (done) {
+            rounds++;
+            break;
+        }
+    }
+    delete[] hstatus;
+    if (roundsOut) *roundsOut = rounds;
+    return rc;
+}

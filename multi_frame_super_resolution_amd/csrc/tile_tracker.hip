@@ -1,0 +1,764 @@
+// tile_tracker.hip -- tile-based shift tracker, kernel-shape and finishing
+// stages.
+// Behavioural spec: reference test_opencv/kernel.cu:116-891.
+//
+// MI355X notes:
+//  * squaredSum / findMinimum are "one THREAD per tile, serial loop" in the
+//    reference (kernel.cu:126-141, :521-541).  Here one 64-lane WAVEFRONT owns a
+//    tile and reduces with DPP/shuffle butterflies; findMinimum's argmin keeps
+//    the serial semantics (first strict minimum) by reducing (value, index)
+//    pairs with index as tie-break, so its result is bit-identical.
+//  * trackTilesFused evaluates the whole B1..B7 chain for one tile inside one
+//    workgroup from LDS (no FFT, no tile stacks in HBM).
+#include <cfloat>
+
+#include "common.hpp"
+
+// ---- wavefront reductions -----------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// (value, index) minimum; ties -> lower index (== first strict minimum of a serial scan)
+__device__ __forceinline__ void wave_argmin(float& v, int& idx)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(v, off, 64);
+        const int oi = __shfl_xor(idx, off, 64);
+        const bool take = (ov < v) || (ov == v && oi < idx);
+        v = take ? ov : v;
+        idx = take ? oi : idx;
+    }
+}
+
+// ---- B3: squaredSum (kernel.cu:119-143) ---------------------------------------
+// one wavefront per tile; lane-strided partial sums + butterfly.  Summation
+// order differs from the serial reference loop: equal within fp32 rounding.
+__global__ void __launch_bounds__(256) k_squaredSum(const float* __restrict__ inTiles, float* __restrict__ outValues,
+                                                   int maxShift, int tileSize, int tileCount)
+{
+    const int lane = threadIdx.x & 63;
+    const int tileIdx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tileIdx >= tileCount) return;
+    const int L = tileSize + 2 * maxShift;
+    const float* t = inTiles + (size_t)tileIdx * L * L;
+    float sum = 0;
+    for (int i = lane; i < tileSize * tileSize; i += 64) {
+        const int y = i / tileSize, x = i - y * tileSize;
+        const float p = t[(y + maxShift) * L + x + maxShift];
+        sum += p * p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) outValues[tileIdx] = sum;
+}
+
+extern "C" int mfsr_squaredSum(const float* inTiles, float* outValues, int maxShift, int tileSize, int tileCount,
+                               mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(inTiles && outValues && maxShift >= 0 && tileSize > 0 && tileCount > 0);
+    hipLaunchKernelGGL(k_squaredSum, dim3(mfsr_cdiv(tileCount, 4)), dim3(256), 0, mfsr_s(stream), inTiles, outValues,
+                       maxShift, tileSize, tileCount);
+    return mfsr_launch_status("squaredSum");
+}
+
+// ---- B4: boxFilterWithBorderX / Y (kernel.cu:149-218) --------------------------
+// One workgroup per (tile, row|column); the line is staged in LDS once and
+// every lane sums its window from LDS in the reference's ascending order, so the
+// result is bit-identical.
+template <bool ALONG_X>
+__global__ void __launch_bounds__(128) k_boxFilterWithBorder(const float* __restrict__ inTiles, float* __restrict__ outTiles,
+                                                            int maxShift, int tileSize, int tileCount)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_line[];
+    const int L = tileSize + 2 * maxShift;
+    const int line = blockIdx.x;  // row (X filter) or column (Y filter)
+    const int tileIdx = blockIdx.y;
+    if (tileIdx >= tileCount) return;
+    const float* t = inTiles + (size_t)tileIdx * L * L;
+    float* o = outTiles + (size_t)tileIdx * L * L;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) s_line[i] = ALONG_X ? t[line * L + i] : t[i * L + line];
+    __syncthreads();
+    for (int p = threadIdx.x; p < L; p += blockDim.x) {
+        float outVal = 0;
+        if (p >= tileSize / 2 && p <= maxShift * 2 + tileSize / 2) {
+            for (int shift = -tileSize / 2; shift < tileSize / 2; shift++) {
+                const float v = s_line[p + shift];
+                outVal += ALONG_X ? v * v : v;  // X squares its input (:177), Y does not (:214)
+            }
+        }
+        if (ALONG_X)
+            o[line * L + p] = outVal;
+        else
+            o[p * L + line] = outVal;
+    }
+}
+
+static int box_filter_launch(bool alongX, const float* inTiles, float* outTiles, int maxShift, int tileSize, int tileCount,
+                             mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(inTiles && outTiles && maxShift >= 0 && tileSize > 0 && tileCount > 0 && tileCount <= 65535);
+    const int L = tileSize + 2 * maxShift;
+    dim3 grid(L, tileCount), block(128);
+    if (alongX)
+        hipLaunchKernelGGL(k_boxFilterWithBorder<true>, grid, block, L * sizeof(float), mfsr_s(stream), inTiles, outTiles,
+                           maxShift, tileSize, tileCount);
+    else
+        hipLaunchKernelGGL(k_boxFilterWithBorder<false>, grid, block, L * sizeof(float), mfsr_s(stream), inTiles, outTiles,
+                           maxShift, tileSize, tileCount);
+    return mfsr_launch_status(alongX ? "boxFilterWithBorderX" : "boxFilterWithBorderY");
+}
+
+extern "C" int mfsr_boxFilterWithBorderX(const float* inTiles, float* outTiles, int maxShift, int tileSize, int tileCount,
+                                         mfsr_stream_t stream)
+{
+    return box_filter_launch(true, inTiles, outTiles, maxShift, tileSize, tileCount, stream);
+}
+extern "C" int mfsr_boxFilterWithBorderY(const float* inTiles, float* outTiles, int maxShift, int tileSize, int tileCount,
+                                         mfsr_stream_t stream)
+{
+    return box_filter_launch(false, inTiles, outTiles, maxShift, tileSize, tileCount, stream);
+}
+
+// ---- B6: normalizedCC (kernel.cu:227-259) -------------------------------------
+__global__ void __launch_bounds__(256)
+    k_normalizedCC(const float* __restrict__ ccImage, const float* __restrict__ squaredTemplate,
+                   const float* __restrict__ boxFilteredImage, float* __restrict__ shiftImage, int maxShift, int tileSize,
+                   int tileCount)
+{
+    const int R = 2 * maxShift + 1;
+    const int L = tileSize + 2 * maxShift;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tileIdx = blockIdx.y;
+    if (i >= R * R || tileIdx >= tileCount) return;
+    const int pxY = i / R, pxX = i - pxY * R;  // pxX,pxY <= 2*maxShift: the '>' guard of :240
+    const int shiftX = pxX - maxShift, shiftY = pxY - maxShift;
+    const int fftShiftX = shiftX < 0 ? L + shiftX : shiftX;
+    const int fftShiftY = shiftY < 0 ? L + shiftY : shiftY;
+    const size_t base = (size_t)tileIdx * L * L;
+    const float cc = ccImage[base + (size_t)fftShiftY * L + fftShiftX];
+    const float bf = boxFilteredImage[base + (size_t)(L / 2 + shiftY) * L + (L / 2 + shiftX)];
+    shiftImage[(size_t)tileIdx * R * R + i] = squaredTemplate[tileIdx] + bf - 2 * cc;
+}
+
+extern "C" int mfsr_normalizedCC(const float* ccImage, const float* squaredTemplate, const float* boxFilteredImage,
+                                 float* shiftImage, int maxShift, int tileSize, int tileCount, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(ccImage && squaredTemplate && boxFilteredImage && shiftImage);
+    MFSR_REQUIRE(maxShift >= 0 && tileSize > 0 && tileCount > 0 && tileCount <= 65535);
+    const int R = 2 * maxShift + 1;
+    hipLaunchKernelGGL(k_normalizedCC, dim3(mfsr_cdiv(R * R, 256), tileCount), dim3(256), 0, mfsr_s(stream), ccImage,
+                       squaredTemplate, boxFilteredImage, shiftImage, maxShift, tileSize, tileCount);
+    return mfsr_launch_status("normalizedCC");
+}
+
+// ---- B1/B2: convertToTilesOverlapBorder / PreShift (kernel.cu:265-378) ---------
+// source pixel of tile-local (pxX,pxY): base shift + rotation about the image
+// centre, roundf, float clamp (:299-313 / :358-372)
+__device__ __forceinline__ float tile_fetch(const float* __restrict__ inImg, int imgWidth, int imgHeight, int imgPitch,
+                                            int tileSize, int tileIdxX, int tileIdxY, int pxX, int pxY, float2 shift,
+                                            float2 baseShift, float baseRotation)
+{
+    const float sf = sinf(baseRotation);
+    const float cf = cosf(baseRotation);
+    shift.x += cf * -baseShift.x - sf * -baseShift.y;
+    shift.y += sf * -baseShift.x + cf * -baseShift.y;
+    const float patchCenterX = (float)(tileIdxX * tileSize + tileSize / 2 - imgWidth / 2);
+    const float patchCenterY = (float)(tileIdxY * tileSize + tileSize / 2 - imgHeight / 2);
+    shift.x += cf * patchCenterX - sf * patchCenterY - patchCenterX;
+    shift.y += sf * patchCenterX + cf * patchCenterY - patchCenterY;
+    int pxInImgX = tileIdxX * tileSize + pxX + f2i(roundf(shift.x));
+    int pxInImgY = tileIdxY * tileSize + pxY + f2i(roundf(shift.y));
+    pxInImgX = f2i(fminf(fmaxf((float)pxInImgX, 0.0f), (float)(imgWidth - 1)));
+    pxInImgY = f2i(fminf(fmaxf((float)pxInImgY, 0.0f), (float)(imgHeight - 1)));
+    return row_ptr(inImg, imgPitch, pxInImgY)[pxInImgX];
+}
+
+template <bool PRESHIFT>
+__global__ void __launch_bounds__(256)
+    k_convertToTiles(const float* __restrict__ inImg, float* __restrict__ outTiles, const float2* __restrict__ preShift,
+                     int preShiftPitch, int imgWidth, int imgHeight, int imgPitch, int maxShift, int tileSize,
+                     int tileCountX, int tileCountY, float2 baseShift, float baseRotation)
+{
+    const int L = tileSize + 2 * maxShift;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tileIdx = blockIdx.y;
+    if (i >= L * L || tileIdx >= tileCountX * tileCountY) return;
+    const int pxY = i / L, pxX = i - pxY * L;
+    const size_t o = (size_t)tileIdx * L * L + i;
+    if (!PRESHIFT && (pxX < maxShift || pxY < maxShift || pxX >= tileSize + maxShift || pxY >= tileSize + maxShift)) {
+        outTiles[o] = 0;  // :286-290
+        return;
+    }
+    const int tileIdxY = tileIdx / tileCountX;
+    const int tileIdxX = tileIdx - tileIdxY * tileCountX;
+    float2 shift = make_float2(0.0f, 0.0f);
+    if (PRESHIFT) shift = row_ptr(preShift, preShiftPitch, tileIdxY)[tileIdxX];
+    outTiles[o] = tile_fetch(inImg, imgWidth, imgHeight, imgPitch, tileSize, tileIdxX, tileIdxY, pxX, pxY, shift,
+                             baseShift, baseRotation);
+}
+
+extern "C" int mfsr_convertToTilesOverlapBorder(const float* inImg, float* outTiles, int imgWidth, int imgHeight,
+                                                int imgPitch, int maxShift, int tileSize, int tileCountX, int tileCountY,
+                                                mfsr_float2 baseShift, float baseRotation, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(inImg && outTiles && imgWidth > 0 && imgHeight > 0 && (long long)imgPitch >= 4LL * imgWidth);
+    MFSR_REQUIRE((imgPitch & 3) == 0 && maxShift >= 0 && tileSize > 0 && tileCountX > 0 && tileCountY > 0);
+    MFSR_REQUIRE((long long)tileCountX * tileCountY <= 65535);
+    const int L = tileSize + 2 * maxShift;
+    hipLaunchKernelGGL(k_convertToTiles<false>, dim3(mfsr_cdiv(L * L, 256), tileCountX * tileCountY), dim3(256), 0,
+                       mfsr_s(stream), inImg, outTiles, (const float2*)nullptr, 0, imgWidth, imgHeight, imgPitch, maxShift,
+                       tileSize, tileCountX, tileCountY, make_float2(baseShift.x, baseShift.y), baseRotation);
+    return mfsr_launch_status("convertToTilesOverlapBorder");
+}
+
+extern "C" int mfsr_convertToTilesOverlapPreShift(const float* inImg, float* outTiles, const mfsr_float2* preShift,
+                                                  int preShiftPitch, int imgWidth, int imgHeight, int imgPitch,
+                                                  int maxShift, int tileSize, int tileCountX, int tileCountY,
+                                                  mfsr_float2 baseShift, float baseRotation, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(inImg && outTiles && preShift && imgWidth > 0 && imgHeight > 0 && (long long)imgPitch >= 4LL * imgWidth);
+    MFSR_REQUIRE((imgPitch & 3) == 0 && maxShift >= 0 && tileSize > 0 && tileCountX > 0 && tileCountY > 0);
+    MFSR_REQUIRE((long long)preShiftPitch >= 8LL * tileCountX && (preShiftPitch & 7) == 0 && ((uintptr_t)preShift & 7) == 0);
+    MFSR_REQUIRE((long long)tileCountX * tileCountY <= 65535);
+    const int L = tileSize + 2 * maxShift;
+    hipLaunchKernelGGL(k_convertToTiles<true>, dim3(mfsr_cdiv(L * L, 256), tileCountX * tileCountY), dim3(256), 0,
+                       mfsr_s(stream), inImg, outTiles, (const float2*)preShift, preShiftPitch, imgWidth, imgHeight,
+                       imgPitch, maxShift, tileSize, tileCountX, tileCountY, make_float2(baseShift.x, baseShift.y),
+                       baseRotation);
+    return mfsr_launch_status("convertToTilesOverlapPreShift");
+}
+
+// ---- B5: conjugateComplexMulKernel (kernel.cu:485-501) -------------------------
+__global__ void __launch_bounds__(256) k_conjugateComplexMul(const float2* __restrict__ aIn, float2* __restrict__ bInOut,
+                                                            int maxElem)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= maxElem) return;
+    float2 valA = aIn[idx];
+    valA.y = -valA.y;
+    const float2 valB = bInOut[idx];
+    float2 res;
+    res.x = valA.x * valB.x - valA.y * valB.y;
+    res.y = valA.x * valB.y + valA.y * valB.x;
+    bInOut[idx] = res;
+}
+
+extern "C" int mfsr_conjugateComplexMulKernel(const mfsr_float2* aIn, mfsr_float2* bInOut, int maxElem,
+                                              mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(aIn && bInOut && maxElem > 0 && ((uintptr_t)aIn & 7) == 0 && ((uintptr_t)bInOut & 7) == 0);
+    hipLaunchKernelGGL(k_conjugateComplexMul, dim3(mfsr_cdiv(maxElem, 256)), dim3(256), 0, mfsr_s(stream),
+                       (const float2*)aIn, (float2*)bInOut, maxElem);
+    return mfsr_launch_status("conjugateComplexMulKernel");
+}
+
+// ---- B7: findMinimum (kernel.cu:503-636) ---------------------------------------
+__constant__ float c_FA11[9] = {1.0f / 4.0f, -2.0f / 4.0f, 1.0f / 4.0f, 2.0f / 4.0f, -4.0f / 4.0f,
+                                2.0f / 4.0f, 1.0f / 4.0f,  -2.0f / 4.0f, 1.0f / 4.0f};
+__constant__ float c_FA22[9] = {1.0f / 4.0f,  2.0f / 4.0f, 1.0f / 4.0f, -2.0f / 4.0f, -4.0f / 4.0f,
+                                -2.0f / 4.0f, 1.0f / 4.0f, 2.0f / 4.0f, 1.0f / 4.0f};
+__constant__ float c_FA12[9] = {1.0f / 4.0f, 0.0f / 4.0f,  -1.0f / 4.0f, 0.0f / 4.0f, 0.0f / 4.0f,
+                                0.0f / 4.0f, -1.0f / 4.0f, 0.0f / 4.0f,  1.0f / 4.0f};
+__constant__ float c_Fb1[9] = {-1.0f / 8.0f, 0.0f / 8.0f,  1.0f / 8.0f, -2.0f / 8.0f, 0.0f / 8.0f,
+                               2.0f / 8.0f,  -1.0f / 8.0f, 0.0f / 8.0f, 1.0f / 8.0f};
+__constant__ float c_Fb2[9] = {-1.0f / 8.0f, -2.0f / 8.0f, -1.0f / 8.0f, 0.0f / 8.0f, 0.0f / 8.0f,
+                               0.0f / 8.0f,  1.0f / 8.0f,  2.0f / 8.0f,  1.0f / 8.0f};
+
+// The wavefront-wide part: min / argmin / max over a (2S+1)^2 distance image that
+// `img` points at (global or LDS).  Every lane returns the same values.
+template <typename Ptr>
+__device__ __forceinline__ void wave_min_argmin_max(Ptr img, int count, int lane, float& minVal, int& minIdx,
+                                                    float& maxVal)
+{
+    minVal = FLT_MAX;
+    maxVal = -FLT_MAX;
+    minIdx = 0x7fffffff;
+    for (int i = lane; i < count; i += 64) {
+        const float val = img[i];
+        maxVal = fmaxf(maxVal, val);
+        if (val < minVal) {
+            minVal = val;
+            minIdx = i;
+        }
+    }
+    wave_argmin(minVal, minIdx);
+    maxVal = wave_max(maxVal);
+    if (minIdx == 0x7fffffff) minIdx = -1;  // nothing below FLT_MAX (serial loop leaves -1, :530)
+}
+
+// The scalar part of findMinimum (:543-633): sub-pixel quadratic fit.
+template <typename Ptr>
+__device__ __forceinline__ float2 subpixel_minimum(Ptr img, int maxShift, float minVal, int minIdx, float maxVal,
+                                                   float threshold)
+{
+    const int R = 2 * maxShift + 1;
+    float2 coord;
+    coord.y = (float)(minIdx / R);
+    coord.x = (float)minIdx - coord.y * (float)R;
+    if (coord.x < 1 || coord.y < 1 || coord.x >= 2 * maxShift || coord.y >= 2 * maxShift) {
+        coord.x = 0;
+        coord.y = 0;
+    } else {
+        float A11 = 0, A22 = 0, A12 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int r = i / 3, c = i % 3;
+            const float v = img[minIdx + (c - 1) + (r - 1) * R];
+            A11 += c_FA11[i] * v;
+            A22 += c_FA22[i] * v;
+            A12 += c_FA12[i] * v;
+            b1 += c_Fb1[i] * v;
+            b2 += c_Fb2[i] * v;
+        }
+        A11 = fmaxf(A11, 0.0f);
+        A22 = fmaxf(A22, 0.0f);
+        float detA = A11 * A22 - A12 * A12;
+        if (detA < 0) {
+            A12 = 0;
+            detA = A11 * A22;
+        }
+        if (detA != 0) {
+            float muX = (A22 * b1 - A12 * b2) / detA;
+            float muY = (A11 * b2 - A12 * b1) / detA;
+            if (fabsf(muX) > 1) muX = 0;
+            if (fabsf(muY) > 1) muY = 0;
+            coord.x -= muX;
+            coord.y -= muY;
+        }
+        coord.x -= (float)maxShift;
+        coord.y -= (float)maxShift;
+    }
+    if (threshold + minVal > maxVal) {
+        coord.x = 0;
+        coord.y = 0;
+    }
+    return coord;
+}
+
+__global__ void __launch_bounds__(256)
+    k_findMinimum(const float* __restrict__ shiftImage, float2* __restrict__ coordinates, int coordinatesPitch,
+                  int maxShift, int tileCount, int tileCountX, float threshold)
+{
+    const int lane = threadIdx.x & 63;
+    const int tileIdx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tileIdx >= tileCount) return;
+    const int R = 2 * maxShift + 1;
+    const float* img = shiftImage + (size_t)tileIdx * R * R;
+    float minVal, maxVal;
+    int minIdx;
+    wave_min_argmin_max(img, R * R, lane, minVal, minIdx, maxVal);
+    if (lane == 0) {
+        const float2 coord = subpixel_minimum(img, maxShift, minVal, minIdx, maxVal, threshold);
+        const int tileIdxY = tileIdx / tileCountX;
+        const int tileIdxX = tileIdx - tileIdxY * tileCountX;
+        row_ptr(coordinates, coordinatesPitch, tileIdxY)[tileIdxX] = coord;
+    }
+}
+
+extern "C" int mfsr_findMinimum(const float* shiftImage, mfsr_float2* coordinates, int coordinatesPitch, int maxShift,
+                                int tileCount, int tileCountX, float threshold, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(shiftImage && coordinates && maxShift >= 0 && tileCount > 0 && tileCountX > 0);
+    MFSR_REQUIRE((long long)coordinatesPitch >= 8LL * tileCountX && (coordinatesPitch & 7) == 0 &&
+                 ((uintptr_t)coordinates & 7) == 0);
+    hipLaunchKernelGGL(k_findMinimum, dim3(mfsr_cdiv(tileCount, 4)), dim3(256), 0, mfsr_s(stream), shiftImage,
+                       (float2*)coordinates, coordinatesPitch, maxShift, tileCount, tileCountX, threshold);
+    return mfsr_launch_status("findMinimum");
+}
+
+// ---- B8: UpSampleShifts (kernel.cu:642-688) ------------------------------------
+__global__ void __launch_bounds__(256)
+    k_UpSampleShifts(const float2* __restrict__ inShift, float2* __restrict__ outShift, int inPitch, int outPitch,
+                     int oldLevel, int newLevel, int oldCountX, int oldCountY, int newCountX, int newCountY,
+                     int oldTileSize, int newTileSize)
+{
+    const int newBlockX = blockIdx.x * blockDim.x + threadIdx.x;
+    const int newBlockY = blockIdx.y * blockDim.y + threadIdx.y;
+    if (newBlockX >= newCountX || newBlockY >= newCountY) return;
+    const float factor = (float)oldLevel * (float)oldTileSize / (float)(newLevel * newTileSize);
+    const float oldX = (float)newBlockX / factor;
+    const float oldY = (float)newBlockY / factor;
+    int oldXMin = f2i(floorf(oldX)), oldXMax = f2i(ceilf(oldX));
+    int oldYMin = f2i(floorf(oldY)), oldYMax = f2i(ceilf(oldY));
+    oldXMin = min(oldXMin, oldCountX - 1);
+    oldXMax = min(oldXMax, oldCountX - 1);
+    oldYMin = min(oldYMin, oldCountY - 1);
+    oldYMax = min(oldYMax, oldCountY - 1);
+    const float2 oldMinMin = row_ptr(inShift, inPitch, oldYMin)[oldXMin];
+    const float2 oldMaxMin = row_ptr(inShift, inPitch, oldYMin)[oldXMax];
+    const float2 oldMinMax = row_ptr(inShift, inPitch, oldYMax)[oldXMin];
+    const float2 oldMaxMax = row_ptr(inShift, inPitch, oldYMax)[oldXMax];
+    const float wx = 1.0f - ((float)oldXMax - oldX);
+    const float wy = 1.0f - ((float)oldYMax - oldY);
+    float temp1 = oldMinMin.x + (oldMaxMin.x - oldMinMin.x) * wx;
+    float temp2 = oldMinMax.x + (oldMaxMax.x - oldMinMax.x) * wx;
+    float2 old;
+    old.x = temp1 + (temp2 - temp1) * wy;
+    temp1 = oldMinMin.y + (oldMaxMin.y - oldMinMin.y) * wx;
+    temp2 = oldMinMax.y + (oldMaxMax.y - oldMinMax.y) * wx;
+    old.y = temp1 + (temp2 - temp1) * wy;
+    old.x *= (float)oldLevel / (float)newLevel;
+    old.y *= (float)oldLevel / (float)newLevel;
+    row_ptr(outShift, outPitch, newBlockY)[newBlockX] = old;
+}
+
+extern "C" int mfsr_UpSampleShifts(const mfsr_float2* inShift, mfsr_float2* outShift, int inPitch, int outPitch,
+                                   int oldLevel, int newLevel, int oldCountX, int oldCountY, int newCountX,
+                                   int newCountY, int oldTileSize, int newTileSize, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(inShift && outShift && oldLevel > 0 && newLevel > 0 && oldCountX > 0 && oldCountY > 0);
+    MFSR_REQUIRE(newCountX > 0 && newCountY > 0 && oldTileSize > 0 && newTileSize > 0);
+    MFSR_REQUIRE((long long)inPitch >= 8LL * oldCountX && (long long)outPitch >= 8LL * newCountX);
+    MFSR_REQUIRE((inPitch & 7) == 0 && (outPitch & 7) == 0 && ((uintptr_t)inShift & 7) == 0 && ((uintptr_t)outShift & 7) == 0);
+    dim3 block(64, 4), grid(mfsr_cdiv(newCountX, 64), mfsr_cdiv(newCountY, 4));
+    hipLaunchKernelGGL(k_UpSampleShifts, grid, block, 0, mfsr_s(stream), (const float2*)inShift, (float2*)outShift,
+                       inPitch, outPitch, oldLevel, newLevel, oldCountX, oldCountY, newCountX, newCountY, oldTileSize,
+                       newTileSize);
+    return mfsr_launch_status("UpSampleShifts");
+}
+
+// ---- E2: ComputeStructureTensor (kernel.cu:691-715) ----------------------------
+__global__ void __launch_bounds__(256) k_ComputeStructureTensor(const float* __restrict__ imgDx,
+                                                               const float* __restrict__ imgDy, pix3* __restrict__ outImg,
+                                                               int imgWidth, int imgHeight, int imgDxDyPitch,
+                                                               int imgOutPitch)
+{
+    const int pxX = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pxY = blockIdx.y * blockDim.y + threadIdx.y;
+    if (pxX >= imgWidth || pxY >= imgHeight) return;
+    const float dx = row_ptr(imgDx, imgDxDyPitch, pxY)[pxX];
+    const float dy = row_ptr(imgDy, imgDxDyPitch, pxY)[pxX];
+    pix3 val = {dx * dx, dy * dy, dx * dy};
+    row_ptr(outImg, imgOutPitch, pxY)[pxX] = val;
+}
+
+extern "C" int mfsr_ComputeStructureTensor(const float* imgDx, const float* imgDy, mfsr_float3* outImg, int imgWidth,
+                                           int imgHeight, int imgDxDyPitch, int imgOutPitch, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(imgDx && imgDy && outImg && imgWidth > 0 && imgHeight > 0);
+    MFSR_REQUIRE((long long)imgDxDyPitch >= 4LL * imgWidth && (long long)imgOutPitch >= 12LL * imgWidth);
+    MFSR_REQUIRE((imgDxDyPitch & 3) == 0 && (imgOutPitch & 3) == 0);
+    dim3 block(64, 4), grid(mfsr_cdiv(imgWidth, 64), mfsr_cdiv(imgHeight, 4));
+    hipLaunchKernelGGL(k_ComputeStructureTensor, grid, block, 0, mfsr_s(stream), imgDx, imgDy, (pix3*)outImg, imgWidth,
+                       imgHeight, imgDxDyPitch, imgOutPitch);
+    return mfsr_launch_status("ComputeStructureTensor");
+}
+
+// ---- E3: ComputeKernelParam (kernel.cu:718-790) --------------------------------
+__device__ __forceinline__ pix3 kernel_param(pix3 grad, float Dth, float Dtr, float kDetail, float kDenoise,
+                                             float kStretch, float kShrink)
+{
+    const float a11 = grad.x, a22 = grad.y, a12 = grad.z;
+    const float help = sqrtf((a22 - a11) * (a22 - a11) + 4.0f * a12 * a12);
+    float c = 2.0f * a12;
+    float s = a22 - a11 + help;
+    const float norm = sqrtf(c * c + s * s);
+    if (norm > 0) {
+        c /= norm;
+        s /= norm;
+    } else {
+        c = 1;
+        s = 0;
+    }
+    const float lam1 = (a11 + a22 + help) / 2.0f;
+    const float lam2 = (a11 + a22 - help) / 2.0f;
+    const float A = 1 + sqrtf((lam1 - lam2) * (lam1 - lam2) / ((lam1 + lam2) * (lam1 + lam2)));
+    float D = 1 - sqrtf(lam1) / Dtr + Dth;
+    D = fmaxf(fminf(1.0f, D), 0.0f);
+    const float k1h = kDetail * kStretch * A;
+    const float k2h = kDetail / kShrink * A;
+    float k1 = ((1.0f - D) * k1h + D * kDetail * kDenoise);
+    float k2 = ((1.0f - D) * k2h + D * kDetail * kDenoise);
+    k1 *= k1;
+    k2 *= k2;
+    const float x2 = c, y2 = s, x1 = s, y1 = -c;
+    const float b11 = k1 * x1 * x1 + x2 * x2 * k2;
+    const float b12 = k1 * x1 * y1 + x2 * y2 * k2;
+    const float b22 = k1 * y1 * y1 + y2 * y2 * k2;
+    const float det = b11 * b22 - b12 * b12 + 0.0000000001f;
+    pix3 kernel = {b22 / det, b11 / det, -b12 / det};
+    return kernel;
+}
+
+__global__ void __launch_bounds__(256) k_ComputeKernelParam(pix3* __restrict__ kernelImg, int imgWidth, int imgHeight,
+                                                           int imgOutPitch, float Dth, float Dtr, float kDetail,
+                                                           float kDenoise, float kStretch, float kShrink)
+{
+    const int pxX = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pxY = blockIdx.y * blockDim.y + threadIdx.y;
+    if (pxX >= imgWidth || pxY >= imgHeight) return;
+    pix3* p = row_ptr(kernelImg, imgOutPitch, pxY) + pxX;
+    *p = kernel_param(*p, Dth, Dtr, kDetail, kDenoise, kStretch, kShrink);
+}
+
+extern "C" int mfsr_ComputeKernelParam(mfsr_float3* kernelImg, int imgWidth, int imgHeight, int imgOutPitch, float Dth,
+                                       float Dtr, float kDetail, float kDenoise, float kStretch, float kShrink,
+                                       mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(kernelImg && imgWidth > 0 && imgHeight > 0 && (long long)imgOutPitch >= 12LL * imgWidth);
+    MFSR_REQUIRE((imgOutPitch & 3) == 0);
+    dim3 block(64, 4), grid(mfsr_cdiv(imgWidth, 64), mfsr_cdiv(imgHeight, 4));
+    hipLaunchKernelGGL(k_ComputeKernelParam, grid, block, 0, mfsr_s(stream), (pix3*)kernelImg, imgWidth, imgHeight,
+                       imgOutPitch, Dth, Dtr, kDetail, kDenoise, kStretch, kShrink);
+    return mfsr_launch_status("ComputeKernelParam");
+}
+
+// ---- H2: GammasRGB (kernel.cu:380-422) ------------------------------------------
+__device__ __forceinline__ float apply_srgb_gamma(float valIn)
+{
+    if (valIn <= 0.0031308f) return 12.92f * valIn;
+    return (1.0f + 0.055f) * powf(valIn, 1.0f / 2.4f) - 0.055f;
+}
+
+__device__ __forceinline__ float gamma_channel(float v)
+{
+    if (isnan(v)) v = 0;
+    v = fmaxf(fminf(v, 1.0f), 0.0f);
+    return apply_srgb_gamma(v);
+}
+
+__global__ void __launch_bounds__(256) k_GammasRGB(pix3* __restrict__ inOutImg, int imgWidth, int imgHeight, int imgPitch)
+{
+    const int pxX = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pxY = blockIdx.y * blockDim.y + threadIdx.y;
+    if (pxX >= imgWidth || pxY >= imgHeight) return;
+    pix3* p = row_ptr(inOutImg, imgPitch, pxY) + pxX;
+    pix3 val = *p;
+    val.x = gamma_channel(val.x);
+    val.y = gamma_channel(val.y);
+    val.z = gamma_channel(val.z);
+    *p = val;
+}
+
+extern "C" int mfsr_GammasRGB(mfsr_float3* inOutImg, int imgWidth, int imgHeight, int imgPitch, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(inOutImg && imgWidth > 0 && imgHeight > 0 && (long long)imgPitch >= 12LL * imgWidth && (imgPitch & 3) == 0);
+    dim3 block(64, 4), grid(mfsr_cdiv(imgWidth, 64), mfsr_cdiv(imgHeight, 4));
+    hipLaunchKernelGGL(k_GammasRGB, grid, block, 0, mfsr_s(stream), (pix3*)inOutImg, imgWidth, imgHeight, imgPitch);
+    return mfsr_launch_status("GammasRGB");
+}
+
+// ---- H1: ApplyWeighting (kernel.cu:426-481) -------------------------------------
+__device__ __forceinline__ float apply_weight(float inout, float val, float w, float threshold)
+{
+    if (w < threshold) {
+        val += inout;
+        w += 1;
+    }
+    inout = 0;
+    if (w != 0) inout = val / w;
+    return inout;
+}
+
+__global__ void __launch_bounds__(256) k_ApplyWeighting(pix3* __restrict__ inOutImg, const pix3* __restrict__ finalImg,
+                                                       const pix3* __restrict__ weight, int imgWidth, int imgHeight,
+                                                       int imgPitch, float threshold)
+{
+    const int pxX = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pxY = blockIdx.y * blockDim.y + threadIdx.y;
+    if (pxX >= imgWidth || pxY >= imgHeight) return;
+    pix3* p = row_ptr(inOutImg, imgPitch, pxY) + pxX;
+    pix3 inout = *p;
+    const pix3 val = row_ptr(finalImg, imgPitch, pxY)[pxX];
+    const pix3 w = row_ptr(weight, imgPitch, pxY)[pxX];
+    inout.x = apply_weight(inout.x, val.x, w.x, threshold);
+    inout.y = apply_weight(inout.y, val.y, w.y, threshold);
+    inout.z = apply_weight(inout.z, val.z, w.z, threshold);
+    *p = inout;
+}
+
+extern "C" int mfsr_ApplyWeighting(mfsr_float3* inOutImg, const mfsr_float3* finalImg, const mfsr_float3* weight,
+                                   int imgWidth, int imgHeight, int imgPitch, float threshold, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(inOutImg && finalImg && weight && imgWidth > 0 && imgHeight > 0);
+    MFSR_REQUIRE((long long)imgPitch >= 12LL * imgWidth && (imgPitch & 3) == 0);
+    dim3 block(64, 4), grid(mfsr_cdiv(imgWidth, 64), mfsr_cdiv(imgHeight, 4));
+    hipLaunchKernelGGL(k_ApplyWeighting, grid, block, 0, mfsr_s(stream), (pix3*)inOutImg, (const pix3*)finalImg,
+                       (const pix3*)weight, imgWidth, imgHeight, imgPitch, threshold);
+    return mfsr_launch_status("ApplyWeighting");
+}
+
+// ---- I1: fourierFilter / fftshift (kernel.cu:794-891) ---------------------------
+__global__ void __launch_bounds__(256) k_fourierFilter(float2* img, size_t stride, int width, int height, float lp,
+                                                      float hp, float lps, float hps, int clearAxis)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= width / 2 + 1) return;
+    if (y >= height) return;
+    float mx = (float)x;
+    float my = (float)y;
+    if (my > (float)height * 0.5f) my = ((float)height - my) * -1.0f;
+    mx /= (float)width;
+    my /= (float)height;
+    const float dist = sqrtf(mx * mx + my * my);
+    float fil = 0;
+    lp = lp - lps;
+    hp = hp + hps;
+    if (lp > 0) {
+        if (dist <= lp) fil = 1;
+    } else {
+        if (dist <= 1.0f) fil = 1;
+    }
+    if (lps > 0) {
+        const float fil2 = (-fil + 1.0f) * expf(-((dist - lp) * (dist - lp) / (2 * lps * lps)));
+        if (fil2 > 0.001f) fil = fil2;
+    }
+    if (lps > 0 && lp == 0 && hp == 0 && hps == 0) fil = expf(-((dist - lp) * (dist - lp) / (2 * lps * lps)));
+    if (hp > 0) {
+        float fil2 = 0;
+        if (dist >= hp) fil2 = 1;
+        fil *= fil2;
+        if (hps > 0) {
+            const float fil3 = (-fil2 + 1.0f) * expf(-((dist - hp) * (dist - hp) / (2 * hps * hps)));
+            if (fil3 > 0.001f) fil = fil3;
+        }
+    }
+    float2* row = (float2*)((char*)img + stride * (size_t)y);
+    float2 erg = row[x];
+    erg.x *= fil;
+    erg.y *= fil;
+    if (x < clearAxis || fabsf(my) * (float)height < (float)clearAxis) {
+        erg.x = 0;
+        erg.y = 0;
+    }
+    row[x] = erg;
+}
+
+extern "C" int mfsr_fourierFilter(mfsr_float2* img, size_t stride, int width, int height, float lp, float hp, float lps,
+                                  float hps, int clearAxis, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(img && width > 0 && height > 0 && stride >= 8ull * (size_t)(width / 2 + 1) && (stride & 7) == 0);
+    MFSR_REQUIRE(((uintptr_t)img & 7) == 0);
+    dim3 block(64, 4), grid(mfsr_cdiv(width / 2 + 1, 64), mfsr_cdiv(height, 4));
+    hipLaunchKernelGGL(k_fourierFilter, grid, block, 0, mfsr_s(stream), (float2*)img, stride, width, height, lp, hp, lps,
+                       hps, clearAxis);
+    return mfsr_launch_status("fourierFilter");
+}
+
+__global__ void __launch_bounds__(256) k_fftshift(float2* fft, int width, int height)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= width) return;
+    if (y >= height) return;
+    const int mx = x - width / 2;
+    const int my = y - height / 2;
+    const float a = 1.0f - (float)(2 * (((mx + my) & 1)));
+    float2 erg = fft[(size_t)y * width + x];
+    erg.x *= a;
+    erg.y *= a;
+    fft[(size_t)y * width + x] = erg;
+}
+
+extern "C" int mfsr_fftshift(mfsr_float2* fft, int width, int height, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(fft && width > 0 && height > 0 && ((uintptr_t)fft & 7) == 0);
+    dim3 block(64, 4), grid(mfsr_cdiv(width, 64), mfsr_cdiv(height, 4));
+    hipLaunchKernelGGL(k_fftshift, grid, block, 0, mfsr_s(stream), (float2*)fft, width, height);
+    return mfsr_launch_status("fftshift");
+}
+
+// ---- fused tracker: B1+B2+B3+B4+cc+B6+B7 (+ rounded pre-shift add) --------------
+// One workgroup per tile.  Threads first gather the T x T reference template and
+// the (T+2S)^2 pre-shifted moved patch into LDS (same source-pixel rule as
+// B1/B2, base shift/rotation = 0).  Then thread k evaluates the L2 distance of
+// candidate shift k = (sy+S)*(2S+1)+(sx+S):
+//     D = sum(ref^2) + sum_window(moved^2) - 2*sum(ref*moved)
+// with every sum taken in the order the unfused chain uses (row-major serial for
+// sum(ref^2) and the correlation; per-row sums then the sum of rows for the box
+// term), so D is bit-identical to squaredSum'(serial)/boxFilter/normalizedCC fed
+// by the direct correlation.  Wavefront 0 then reduces D with shuffles and lane 0
+// runs the quadratic sub-pixel fit.
+__global__ void __launch_bounds__(1024)
+    k_trackTilesFused(const float* __restrict__ refImg, const float* __restrict__ movedImg,
+                      const float2* __restrict__ preShift, int preShiftPitch, float2* __restrict__ coordinates,
+                      int coordinatesPitch, int imgWidth, int imgHeight, int imgPitch, int maxShift, int tileSize,
+                      int tileCountX, int tileCountY, float threshold)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const int T = tileSize, S = maxShift, L = T + 2 * S, R = 2 * S + 1;
+    float* s_ref = s_mem;            // T*T
+    float* s_mov = s_ref + T * T;    // L*L
+    float* s_dist = s_mov + L * L;   // R*R
+    const int tileIdx = blockIdx.x;
+    const int tileIdxY = tileIdx / tileCountX;
+    const int tileIdxX = tileIdx - tileIdxY * tileCountX;
+    const int tid = threadIdx.x;
+
+    float2 pre = make_float2(0.0f, 0.0f);
+    if (preShift) pre = row_ptr(preShift, preShiftPitch, tileIdxY)[tileIdxX];
+    const float2 zero2 = make_float2(0.0f, 0.0f);
+    for (int i = tid; i < T * T; i += blockDim.x) {
+        const int y = i / T, x = i - y * T;
+        s_ref[i] = tile_fetch(refImg, imgWidth, imgHeight, imgPitch, T, tileIdxX, tileIdxY, x + S, y + S, zero2, zero2, 0.0f);
+    }
+    for (int i = tid; i < L * L; i += blockDim.x) {
+        const int y = i / L, x = i - y * L;
+        s_mov[i] = tile_fetch(movedImg, imgWidth, imgHeight, imgPitch, T, tileIdxX, tileIdxY, x, y, pre, zero2, 0.0f);
+    }
+    __syncthreads();
+
+    if (tid < R * R) {
+        const int sy = tid / R, sx = tid - sy * R;  // window origin in the moved patch
+        float sq = 0, cc = 0, box = 0;
+        for (int y = 0; y < T; y++) {
+            const float* mrow = s_mov + (sy + y) * L + sx;
+            const float* rrow = s_ref + y * T;
+            float rowsq = 0;
+            for (int x = 0; x < T; x++) {
+                const float r = rrow[x];
+                const float m = mrow[x];
+                sq += r * r;
+                rowsq += m * m;
+                cc += r * m;
+            }
+            box += rowsq;
+        }
+        s_dist[tid] = sq + box - 2 * cc;
+    }
+    __syncthreads();
+
+    if (tid < 64) {
+        float minVal, maxVal;
+        int minIdx;
+        wave_min_argmin_max(s_dist, R * R, tid, minVal, minIdx, maxVal);
+        if (tid == 0) {
+            float2 coord = subpixel_minimum(s_dist, S, minVal, minIdx, maxVal, threshold);
+            coord.x = roundf(pre.x) + coord.x;
+            coord.y = roundf(pre.y) + coord.y;
+            row_ptr(coordinates, coordinatesPitch, tileIdxY)[tileIdxX] = coord;
+        }
+    }
+}
+
+extern "C" int mfsr_trackTilesFused(const float* refImg, const float* movedImg, const mfsr_float2* preShift,
+                                    int preShiftPitch, mfsr_float2* coordinates, int coordinatesPitch, int imgWidth,
+                                    int imgHeight, int imgPitch, int maxShift, int tileSize, int tileCountX,
+                                    int tileCountY, float threshold, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(refImg && movedImg && coordinates && imgWidth > 0 && imgHeight > 0);
+    MFSR_REQUIRE((long long)imgPitch >= 4LL * imgWidth && (imgPitch & 3) == 0);
+    MFSR_REQUIRE(maxShift >= 1 && maxShift <= 15 && tileSize >= 4 && tileSize <= 128 && tileCountX > 0 && tileCountY > 0);
+    MFSR_REQUIRE((long long)coordinatesPitch >= 8LL * tileCountX && (coordinatesPitch & 7) == 0 &&
+                 ((uintptr_t)coordinates & 7) == 0);
+    if (preShift)
+        MFSR_REQUIRE((long long)preShiftPitch >= 8LL * tileCountX && (preShiftPitch & 7) == 0 && ((uintptr_t)preShift & 7) == 0);
+    const int L = tileSize + 2 * maxShift, R = 2 * maxShift + 1;
+    const size_t lds = sizeof(float) * ((size_t)tileSize * tileSize + (size_t)L * L + (size_t)R * R);
+    if (lds > 64 * 1024) return MFSR_E_UNSUPPORTED;
+    const int threads = ((R * R + 63) / 64) * 64;
+    hipLaunchKernelGGL(k_trackTilesFused, dim3(tileCountX * tileCountY), dim3(threads), lds, mfsr_s(stream), refImg,
+                       movedImg, (const float2*)preShift, preShiftPitch, (float2*)coordinates, coordinatesPitch, imgWidth,
+                       imgHeight, imgPitch, maxShift, tileSize, tileCountX, tileCountY, threshold);
+    return mfsr_launch_status("trackTilesFused");
+}

@@ -1,0 +1,822 @@
+"""GPU parity: every HIP entry point of include/mfsr.h against the CPU oracle on
+the same seeded inputs.
+
+Tolerances (north_star: +-1 LSB on outputs, DeBayer bit-exact):
+  * kernels made of + - * / fabs only (A1-A3, B1-B8 except the wave-sum in
+    squaredSum, C*, E2, H1, box filters, fused tracker) : BIT-EXACT;
+  * kernels with transcendentals (exp, pow, sin/cos/atan2) or re-ordered sums:
+    the tolerance is written next to each assertion.
+"""
+import numpy as np
+import pytest
+
+from tests.kernels import F2, F3, Host, Tex, pitch_of
+
+pytestmark = pytest.mark.gpu
+
+RGGB = [0, 1, 1, 2]
+PATTERNS = {"RGGB": [0, 1, 1, 2], "BGGR": [2, 1, 1, 0], "GRBG": [1, 0, 2, 1], "GBRG": [1, 2, 0, 1]}
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def run_both(orc, hip, fname, make):
+    """make() -> (args, outputs): fresh arrays each time; returns (oracle_outputs, hip_outputs)."""
+    res = []
+    for k in (orc, hip):
+        args, outs = make()
+        k.call(fname, *args)
+        res.append([o.copy() for o in outs])
+    return res
+
+
+def assert_bitexact(a, b, what=""):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    same = (a.view(np.uint32) == b.view(np.uint32)) if a.dtype == np.float32 else (a == b)
+    if a.dtype == np.float32:
+        same = same | (np.isnan(a) & np.isnan(b))
+    assert same.all(), f"{what}: {np.count_nonzero(~same)} of {a.size} elements differ, max |d| = {np.nanmax(np.abs(a - b))}"
+
+
+# ---------------------------------------------------------------- A: DeBayer
+@pytest.mark.parametrize("pat", list(PATTERNS))
+@pytest.mark.parametrize("shape", [(32, 32), (48, 64)])
+def test_deBayersSubSample3(orc, hip, pat, shape):
+    hh, hw = shape
+    orc.set_cfa(PATTERNS[pat])
+    hip.set_cfa(PATTERNS[pat])
+
+    def make():
+        raw = rng(1).integers(0, 4096, (2 * hh, 2 * hw), dtype=np.uint16)
+        out = np.zeros((hh, hw + 3, 3), np.float32)  # odd pitch
+        return (raw, out, 4095.0, hw, hh, pitch_of(out)), [out]
+
+    (o,), (h,) = run_both(orc, hip, "deBayersSubSample3", make)
+    assert_bitexact(o, h, "deBayersSubSample3")
+    assert o[:, :hw].max() > 0
+
+
+@pytest.mark.parametrize("pat", list(PATTERNS))
+def test_deBayer_green_redblue_and_fused(orc, hip, pat):
+    H, W = 40, 72
+    orc.set_cfa(PATTERNS[pat])
+    hip.set_cfa(PATTERNS[pat])
+    bp = F3([256, 250, 260])
+    sc = F3([1 / 3839.0, 1 / 3800.0, 1 / 3850.0])
+    raw16 = rng(2).integers(200, 4096, (H, W), dtype=np.uint16)
+
+    def make():
+        rawf = raw16.astype(np.float32)
+        out = np.zeros((H, W, 3), np.float32)
+        return rawf, out
+
+    outs = []
+    for k in (orc, hip):
+        rawf, out = make()
+        k.call("deBayerGreenKernel", W, H, rawf, pitch_of(rawf), out, pitch_of(out), bp, sc)
+        g = out.copy()
+        k.call("deBayerRedBlueKernel", W, H, rawf, pitch_of(rawf), out, pitch_of(out), bp, sc)
+        outs.append((g, out.copy()))
+    assert_bitexact(outs[0][0], outs[1][0], "deBayerGreenKernel")
+    assert_bitexact(outs[0][1], outs[1][1], "deBayerRedBlueKernel")
+    # border ring untouched
+    assert (outs[1][1][:2] == 0).all() and (outs[1][1][:, :2] == 0).all()
+    # fused A2+A3 == two-launch chain, bit for bit
+    fused = np.zeros((H, W, 3), np.float32)
+    hip.call("deBayerFused", raw16.copy(), fused, pitch_of(fused), W, H, bp, sc)
+    assert_bitexact(outs[0][1], fused, "deBayerFused vs oracle chain")
+
+
+# ---------------------------------------------------------------- G: accumulate
+def _accum_inputs(seed, W, H, hrW, hrH, nan_frac=0.0):
+    r = rng(seed)
+    raw = r.integers(256, 4096, (H, W), dtype=np.uint16)
+    imgOut = r.random((hrH, hrW, 3), dtype=np.float32)
+    tw = r.random((hrH, hrW, 3), dtype=np.float32)
+    mask = r.random(((H + 1) // 2, (W + 1) // 2, 4), dtype=np.float32)
+    if nan_frac:
+        m = r.random(mask.shape) < nan_frac
+        mask[m] = np.nan
+    return raw, imgOut, tw, mask
+
+
+def _kernel_field(seed, h, w, chan):
+    # positive-definite-ish inverse covariances with a few hostile values
+    r = rng(seed)
+    k = np.zeros((h, w, chan), np.float32)
+    k[..., 0] = r.uniform(0.05, 3.0, (h, w))
+    k[..., 1] = r.uniform(0.05, 3.0, (h, w))
+    k[..., 2] = r.uniform(-0.2, 0.2, (h, w))
+    k[0, 0, :3] = np.nan            # -> w non finite -> axis rule (DeBayerKernels.cu:429-430)
+    k[1, 1, :3] = [-50, -50, 0]     # exp overflow -> inf -> axis rule
+    return k
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+def test_accumulateImagesSuperRes_crop(orc, hip, fast):
+    W, H = 96, 64
+    orc.set_cfa(RGGB)
+    hip.set_cfa(RGGB)
+    hip.L.set_accumulate_fast_exp(fast)
+    white, black = F3([3839, 3839, 3839]), F3([256, 256, 256])
+
+    def make():
+        raw, imgOut, tw, mask = _accum_inputs(3, W, H, W, H, nan_frac=0.01)
+        kp = _kernel_field(4, H // 2, W // 2, 4)
+        sh = rng(5).uniform(-3, 3, (H // 2, W // 2, 2)).astype(np.float32)
+        args = (raw, imgOut, tw, mask, Tex(kp), Tex(sh), white, black, W, H, pitch_of(imgOut), pitch_of(mask))
+        return args, [imgOut, tw]
+
+    (oi, ow), (hi, hw_) = run_both(orc, hip, "accumulateImagesSuperRes", make)
+    hip.L.set_accumulate_fast_exp(1)
+    # exp differs by <= 2 ulp (ocml) / ~1e-6 rel (v_exp path); 25 taps of O(1) values
+    tol = 2e-6 if fast == 0 else 2e-5
+    np.testing.assert_allclose(hi, oi, rtol=tol, atol=tol)
+    np.testing.assert_allclose(hw_, ow, rtol=tol, atol=tol)
+    # border ring untouched
+    raw, imgOut, tw, mask = _accum_inputs(3, W, H, W, H, nan_frac=0.01)
+    assert_bitexact(hi[0], imgOut[0])
+    assert_bitexact(hi[:, 0], imgOut[:, 0])
+
+
+@pytest.mark.parametrize("scale", [1, 2, 3, 4])
+def test_accumulateSuperResFull(orc, hip, scale):
+    W, H = 64, 48
+    hrW, hrH = W * scale, H * scale
+    orc.set_cfa(PATTERNS["GRBG"])
+    hip.set_cfa(PATTERNS["GRBG"])
+    hip.L.set_accumulate_fast_exp(0)
+    white, black = F3([3839, 3700, 3900]), F3([256, 260, 250])
+
+    def make():
+        raw, imgOut, tw, mask = _accum_inputs(6 + scale, W, H, hrW, hrH)
+        kp = _kernel_field(7, H // 2, W // 2, 4)
+        sh = rng(8).uniform(-4, 4, (H // 2, W // 2, 2)).astype(np.float32)
+        args = (raw, imgOut, tw, mask, Tex(kp), Tex(sh), white, black, W, H, scale, pitch_of(imgOut), pitch_of(mask))
+        return args, [imgOut, tw]
+
+    (oi, ow), (hi, hw_) = run_both(orc, hip, "accumulateSuperResFull", make)
+    hip.L.set_accumulate_fast_exp(1)
+    np.testing.assert_allclose(hi, oi, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(hw_, ow, rtol=2e-6, atol=2e-6)
+
+
+def test_accumulateImages_x1(orc, hip):
+    W, H = 64, 40
+    orc.set_cfa(RGGB)
+    hip.set_cfa(RGGB)
+    white, black = F3([3839, 3839, 3839]), F3([256, 256, 256])
+
+    def make():
+        raw, imgOut, tw, mask = _accum_inputs(9, W, H, W, H)
+        kp = _kernel_field(10, H, W, 3)
+        sh = rng(11).uniform(-3, 3, (H, W, 2)).astype(np.float32)
+        args = (raw, imgOut, tw, mask, kp, sh, white, black, W, H, pitch_of(imgOut), pitch_of(mask), pitch_of(sh))
+        return args, [imgOut, tw]
+
+    (oi, ow), (hi, hw_) = run_both(orc, hip, "accumulateImages", make)
+    np.testing.assert_allclose(hi, oi, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(hw_, ow, rtol=2e-6, atol=2e-6)
+
+
+# ---------------------------------------------------------------- B: tile tracker
+def _tiles(seed, tiles, T, S):
+    L = T + 2 * S
+    return rng(seed).random((tiles, L, L), dtype=np.float32)
+
+
+def test_squaredSum(orc, hip):
+    T, S, n = 16, 3, 13
+
+    def make():
+        t = _tiles(20, n, T, S)
+        out = np.zeros(n, np.float32)
+        return (t, out, S, T, n), [out]
+
+    (o,), (h,) = run_both(orc, hip, "squaredSum", make)
+    # wavefront reduction re-orders the 256-term sum: fp32 rounding only
+    np.testing.assert_allclose(h, o, rtol=2e-6)
+
+
+@pytest.mark.parametrize("which", ["boxFilterWithBorderX", "boxFilterWithBorderY"])
+def test_boxFilterWithBorder(orc, hip, which):
+    T, S, n = 16, 4, 7
+
+    def make():
+        t = _tiles(21, n, T, S)
+        out = np.full_like(t, -1)
+        return (t, out, S, T, n), [out]
+
+    (o,), (h,) = run_both(orc, hip, which, make)
+    assert_bitexact(o, h, which)
+
+
+def test_normalizedCC_and_crossCorrelate(orc, hip):
+    T, S, n = 16, 3, 5
+    L, R = T + 2 * S, 2 * S + 1
+
+    def make_cc():
+        a, b = _tiles(22, n, T, S), _tiles(23, n, T, S)
+        cc = np.full((n, L, L), -1, np.float32)
+        return (a, b, cc, S, T, n), [cc]
+
+    (occ,), (hcc,) = run_both(orc, hip, "crossCorrelateTiles", make_cc)
+    assert_bitexact(occ, hcc, "crossCorrelateTiles")
+
+    def make():
+        cc = occ.copy()
+        sq = rng(24).random(n, dtype=np.float32) * 50
+        box = _tiles(25, n, T, S) * 50
+        out = np.zeros((n, R, R), np.float32)
+        return (cc, sq, box, out, S, T, n), [out]
+
+    (o,), (h,) = run_both(orc, hip, "normalizedCC", make)
+    assert_bitexact(o, h, "normalizedCC")
+
+
+@pytest.mark.parametrize("rot", [0.0, 0.05])
+def test_convertToTiles(orc, hip, rot):
+    W, H, T, S = 100, 70, 16, 3
+    tcx, tcy = W // T, H // T
+    L = T + 2 * S
+    img = rng(26).random((H, W + 5), dtype=np.float32)
+    base = F2([1.3, -0.7] if rot else [0, 0])
+
+    def make_b():
+        out = np.full((tcx * tcy, L, L), -1, np.float32)
+        return (img, out, W, H, pitch_of(img), S, T, tcx, tcy, base, rot), [out]
+
+    (o,), (h,) = run_both(orc, hip, "convertToTilesOverlapBorder", make_b)
+    if rot == 0.0:
+        assert_bitexact(o, h, "convertToTilesOverlapBorder")
+    else:  # sinf/cosf feed a roundf: identical unless a rounding tie is hit
+        assert np.mean(o != h) < 0.01
+
+    pre = rng(27).uniform(-4, 4, (tcy, tcx, 2)).astype(np.float32)
+
+    def make_p():
+        out = np.full((tcx * tcy, L, L), -1, np.float32)
+        return (img, out, pre, pitch_of(pre), W, H, pitch_of(img), S, T, tcx, tcy, base, rot), [out]
+
+    (o,), (h,) = run_both(orc, hip, "convertToTilesOverlapPreShift", make_p)
+    if rot == 0.0:
+        assert_bitexact(o, h, "convertToTilesOverlapPreShift")
+    else:
+        assert np.mean(o != h) < 0.01
+
+
+def _paraboloid(S, cx, cy, n=1, seed=0):
+    R = 2 * S + 1
+    y, x = np.mgrid[0:R, 0:R].astype(np.float32)
+    img = np.stack([(1.5 * (x - S - cx) ** 2 + 0.8 * (y - S - cy) ** 2 + 0.3 * (x - S - cx) * (y - S - cy) + 2.0)
+                    for _ in range(n)]).astype(np.float32)
+    return img
+
+
+def test_findMinimum(orc, hip):
+    S = 4
+    R = 2 * S + 1
+    tcx, tcy = 5, 3
+    n = tcx * tcy
+    r = rng(28)
+    imgs = r.random((n, R, R), dtype=np.float32) * 10
+    imgs[0] = _paraboloid(S, 1.3, -0.6)[0]          # analytic interior minimum
+    imgs[1] = 1.0                                    # flat tile -> (0,0)
+    imgs[2] = _paraboloid(S, 4.0, 0.0)[0]            # minimum on the border ring -> (0,0)
+    imgs[3, 2, 2] = imgs[3, 5, 5] = -5.0             # tie: first strict minimum wins
+    imgs[4] = np.nan                                 # all NaN
+
+    def make():
+        out = np.full((tcy, tcx + 1, 2), 7, np.float32)
+        return (imgs.copy(), out, pitch_of(out), S, n, tcx, 0.5), [out]
+
+    (o,), (h,) = run_both(orc, hip, "findMinimum", make)
+    assert_bitexact(o, h, "findMinimum")
+    np.testing.assert_allclose(o[0, 0], [1.3, -0.6], atol=0.05)  # the quadratic fit recovers the analytic minimum
+    assert (o[0, 1] == 0).all() and (o[0, 2] == 0).all()
+
+
+def test_UpSampleShifts(orc, hip):
+    ocx, ocy, ncx, ncy = 7, 5, 15, 11
+    inS = rng(29).uniform(-5, 5, (ocy, ocx, 2)).astype(np.float32)
+
+    def make():
+        out = np.zeros((ncy, ncx, 2), np.float32)
+        return (inS, out, pitch_of(inS), pitch_of(out), 4, 2, ocx, ocy, ncx, ncy, 16, 16), [out]
+
+    (o,), (h,) = run_both(orc, hip, "UpSampleShifts", make)
+    assert_bitexact(o, h, "UpSampleShifts")
+
+
+@pytest.mark.parametrize("T,S", [(16, 3), (32, 4), (32, 8)])
+def test_trackTilesFused_equals_chain(orc, hip, T, S):
+    """Fused tracker == oracle chain B1,B2,cc,B3,B4x,B4y,B6,B7 + rounded pre-shift add, bit for bit."""
+    W, H = 160, 96
+    tcx, tcy = W // T, H // T
+    n, L, R = tcx * tcy, T + 2 * S, 2 * S + 1
+    r = rng(30)
+    base = r.random((H + 16, W + 16), dtype=np.float32)
+    ref = np.ascontiguousarray(base[8:8 + H, 8:8 + W])
+    mov = np.ascontiguousarray(base[6:6 + H, 9:9 + W])  # moved(p + (-1,+2)) == ref(p)
+    pre = r.uniform(-1.4, 1.4, (tcy, tcx, 2)).astype(np.float32)
+    z = F2([0, 0])
+    rt = np.zeros((n, L, L), np.float32)
+    mt = np.zeros((n, L, L), np.float32)
+    cc = np.zeros((n, L, L), np.float32)
+    bx = np.zeros((n, L, L), np.float32)
+    by = np.zeros((n, L, L), np.float32)
+    sq = np.zeros(n, np.float32)
+    dist = np.zeros((n, R, R), np.float32)
+    coord = np.zeros((tcy, tcx, 2), np.float32)
+    orc.call("convertToTilesOverlapBorder", ref, rt, W, H, pitch_of(ref), S, T, tcx, tcy, z, 0.0)
+    orc.call("convertToTilesOverlapPreShift", mov, mt, pre, pitch_of(pre), W, H, pitch_of(mov), S, T, tcx, tcy, z, 0.0)
+    orc.call("crossCorrelateTiles", rt, mt, cc, S, T, n)
+    orc.call("squaredSum", rt, sq, S, T, n)
+    orc.call("boxFilterWithBorderX", mt, bx, S, T, n)
+    orc.call("boxFilterWithBorderY", bx, by, S, T, n)
+    orc.call("normalizedCC", cc, sq, by, dist, S, T, n)
+    orc.call("findMinimum", dist, coord, pitch_of(coord), S, n, tcx, 0.0)
+    orc.call("addRoundedPreShift", pre, pitch_of(pre), coord, pitch_of(coord), tcx, tcy)
+    got = np.zeros((tcy, tcx, 2), np.float32)
+    hip.call("trackTilesFused", ref, mov, pre, pitch_of(pre), got, pitch_of(got), W, H, pitch_of(ref), S, T, tcx, tcy, 0.0)
+    assert_bitexact(coord, got, "trackTilesFused")
+    # interior tiles recover the true shift (-1, +2)
+    np.testing.assert_allclose(got[1:-1, 1:-1].reshape(-1, 2), np.tile([-1.0, 2.0], ((tcy - 2) * (tcx - 2), 1)), atol=0.05)
+
+
+# ---------------------------------------------------------------- C: shift minimiser
+def _design(n_img, pairs):
+    n1, m = n_img - 1, len(pairs)
+    A = np.zeros((n1, m), np.float32)  # column-major m x n1  ==  C array [n1][m]
+    for r, (a, b) in enumerate(pairs):
+        A[a:b, r] = 1.0
+    return A
+
+
+def test_solve_and_checkForOutliers(orc, hip):
+    n_img, tiles = 6, 37
+    pairs = [(a, b) for a in range(n_img) for b in range(a + 1, n_img)]
+    n1, m = n_img - 1, len(pairs)
+    r = rng(40)
+    d_true = r.uniform(-3, 3, (tiles, n1, 2)).astype(np.float32)
+    A1 = _design(n_img, pairs)
+    meas = np.zeros((tiles, m, 2), np.float32)
+    for k, (a, b) in enumerate(pairs):
+        meas[:, k] = d_true[:, a:b].sum(1)
+    meas += r.normal(0, 0.02, meas.shape).astype(np.float32)
+    meas[3, 4] += 5.0   # outlier
+    meas[7, 0] -= 9.0
+    res = []
+    for k in (orc, hip):
+        A = np.tile(A1[None], (tiles, 1, 1)).copy()
+        ms = meas.copy()
+        one = np.zeros((tiles, n1, 2), np.float32)
+        opt = np.zeros((tiles, 2, m), np.float32)
+        info = np.zeros(tiles, np.int32)
+        status = np.zeros(tiles, np.int32)
+        rounds = 0
+        while True:
+            k.call("solveShiftsBatched", A, ms, one, opt, info, tiles, n_img, m)
+            k.call("checkForOutliers", ms, opt, A, status, info, tiles, n_img, m)
+            rounds += 1
+            if (status < 0).all() or rounds > m:
+                break
+        res.append((A, ms, one, opt, info, status, rounds))
+    for i, nm in enumerate(["shiftMatrix", "measured", "oneToOne", "optimT", "info", "status"]):
+        assert_bitexact(res[0][i], res[1][i], nm)
+    assert res[0][6] == res[1][6] >= 2
+    A, ms, one = res[1][0], res[1][1], res[1][2]
+    assert (ms[3, 4] == 0).all() and (A[3, :, 4] == 0).all()      # the outlier row was dropped
+    np.testing.assert_allclose(one, d_true, atol=0.1)
+
+
+def test_solve_singular_reports_info(orc, hip):
+    n_img, tiles = 4, 3
+    pairs = [(0, 1), (0, 1), (2, 3)]   # image 1->2 never measured: singular normal matrix
+    m = len(pairs)
+    A1 = _design(n_img, pairs)
+
+    def make():
+        A = np.tile(A1[None], (tiles, 1, 1)).copy()
+        ms = rng(41).random((tiles, m, 2), dtype=np.float32)
+        one = np.ones((tiles, n_img - 1, 2), np.float32)
+        opt = np.ones((tiles, 2, m), np.float32)
+        info = np.zeros(tiles, np.int32)
+        return (A, ms, one, opt, info, tiles, n_img, m), [one, opt, info]
+
+    (o1, o2, o3), (h1, h2, h3) = run_both(orc, hip, "solveShiftsBatched", make)
+    assert (o3 != 0).all()
+    assert_bitexact(o3, h3)
+    assert_bitexact(o1, h1)
+    assert_bitexact(o2, h2)
+
+
+def test_minimizeShifts_driver(orc, hip):
+    """The C-ABI loop == the same loop written around the oracle."""
+    import torch
+    n_img, tiles = 5, 11
+    pairs = [(a, b) for a in range(n_img) for b in range(a + 1, n_img)]
+    n1, m = n_img - 1, len(pairs)
+    r = rng(42)
+    meas = r.uniform(-2, 2, (tiles, m, 2)).astype(np.float32)
+    meas[2, 1] += 7
+    A0 = np.tile(_design(n_img, pairs)[None], (tiles, 1, 1)).copy()
+    A, ms = A0.copy(), meas.copy()
+    one = np.zeros((tiles, n1, 2), np.float32)
+    opt = np.zeros((tiles, 2, m), np.float32)
+    info = np.zeros(tiles, np.int32)
+    status = np.zeros(tiles, np.int32)
+    rounds = 0
+    while True:
+        orc.call("solveShiftsBatched", A, ms, one, opt, info, tiles, n_img, m)
+        orc.call("checkForOutliers", ms, opt, A, status, info, tiles, n_img, m)
+        rounds += 1
+        if (status < 0).all():
+            break
+    dev = "cuda:0"
+    tA, tms = torch.from_numpy(A0).to(dev), torch.from_numpy(meas).to(dev)
+    tone, topt = torch.zeros_like(torch.from_numpy(one)).to(dev), torch.zeros((tiles, 2, m), device=dev)
+    tinfo = torch.zeros(tiles, dtype=torch.int32, device=dev)
+    tstat = torch.zeros(tiles, dtype=torch.int32, device=dev)
+    import ctypes
+    nr = ctypes.c_int(0)
+    hip.L.minimizeShifts(tA.data_ptr(), tms.data_ptr(), tone.data_ptr(), topt.data_ptr(), tstat.data_ptr(),
+                         tinfo.data_ptr(), tiles, n_img, m, ctypes.addressof(nr), None)
+    assert nr.value == rounds
+    assert_bitexact(one, tone.cpu().numpy(), "minimizeShifts oneToOne")
+    assert (tstat.cpu().numpy() == -1).all()
+
+
+def test_shift_glue_kernels(orc, hip):
+    n_img, tcx, tcy = 5, 6, 4
+    n1 = n_img - 1
+    tiles = tcx * tcy
+    best = rng(43).uniform(-3, 3, (tiles, n1, 2)).astype(np.float32)
+    for ref, trk in [(0, 3), (4, 1), (2, 2)]:
+        def make():
+            out = np.zeros((tcy, tcx + 2, 2), np.float32)
+            return (out, best, n_img, tcx, tcy, pitch_of(out), ref, trk), [out]
+        (o,), (h,) = run_both(orc, hip, "getOptimalShifts", make)
+        assert_bitexact(o, h, "getOptimalShifts")
+    m = 7
+    mT = rng(44).random((tiles, 2, m), dtype=np.float32)
+    oT = rng(45).random((tiles, 2, n1), dtype=np.float32)
+
+    def make_t():
+        ms = np.zeros((tiles, m, 2), np.float32)
+        one = np.zeros((tiles, n1, 2), np.float32)
+        return (ms, mT, oT, one, tiles, n_img, m), [ms, one]
+    (o1, o2), (h1, h2) = run_both(orc, hip, "transposeShifts", make_t)
+    assert_bitexact(o1, h1)
+    assert_bitexact(o2, h2)
+    np.testing.assert_array_equal(o1[..., 0], mT[:, 0])
+
+    def make_c():
+        mats = rng(46).random((tiles, n1, m), dtype=np.float32)
+        return (mats, tiles, n_img, m), [mats]
+    (o,), (h,) = run_both(orc, hip, "copyShiftMatrix", make_c)
+    assert_bitexact(o, h)
+    assert (h == h[0]).all()
+
+
+def test_concatenate_separate_setPointers(hip):
+    """Pointer-array ABI (ShiftMinimizerKernels.cu:51-55,224,244) on device pointers."""
+    import torch
+    dev = "cuda:0"
+    m, tcx, tcy = 3, 5, 4
+    imgs = [torch.rand(tcy, tcx + i, 2, device=dev) for i in range(m)]
+    ptrs = torch.tensor([t.data_ptr() for t in imgs], dtype=torch.int64, device=dev)
+    pitches = torch.tensor([t.stride(0) * 4 for t in imgs], dtype=torch.int32, device=dev)
+    out = torch.zeros(tcy * tcx, m, 2, device=dev)
+    hip.L.concatenateShifts(ptrs.data_ptr(), pitches.data_ptr(), out.data_ptr(), m, tcx, tcy, None)
+    torch.cuda.synchronize()
+    for k in range(m):
+        assert torch.equal(out[:, k].reshape(tcy, tcx, 2), imgs[k][:, :tcx])
+    back = [torch.zeros_like(t) for t in imgs]
+    bptrs = torch.tensor([t.data_ptr() for t in back], dtype=torch.int64, device=dev)
+    hip.L.separateShifts(out.data_ptr(), bptrs.data_ptr(), pitches.data_ptr(), m, tcx, tcy, None)
+    torch.cuda.synchronize()
+    for k in range(m):
+        assert torch.equal(back[k][:, :tcx], imgs[k][:, :tcx])
+    # setPointers: per-tile base addresses
+    tiles, n_img, mm = 9, 4, 5
+    n1 = n_img - 1
+    arrs = [torch.zeros(tiles, dtype=torch.int64, device=dev) for _ in range(8)]
+    bases = [torch.zeros(tiles * n1 * mm, device=dev), torch.zeros(tiles * n1 * mm, device=dev),
+             torch.zeros(tiles * n1 * n1, device=dev), torch.zeros(tiles * n1 * n1, device=dev),
+             torch.zeros(tiles * n1 * mm, device=dev), torch.zeros(tiles * n1 * 2, device=dev),
+             torch.zeros(tiles * mm * 2, device=dev), torch.zeros(tiles * mm * 2, device=dev)]
+    hip.L.setPointers(*[a.data_ptr() for a in arrs], *[b.data_ptr() for b in bases], tiles, n_img, mm, None)
+    torch.cuda.synchronize()
+    strides = [n1 * mm * 4, n1 * mm * 4, n1 * n1 * 4, n1 * n1 * 4, n1 * mm * 4, n1 * 8, mm * 8, mm * 8]
+    # array order: matrix, safe, square, inverted, solved, oneToOne, MEASURED, OPTIM (:51-53);
+    # base order: ..., shiftsOneToOne, shiftsMeasured, shiftsOptim (:54-55)
+    for a, b, s in zip(arrs, bases, strides):
+        want = b.data_ptr() + torch.arange(tiles, dtype=torch.int64) * s
+        assert torch.equal(a.cpu(), want)
+
+
+# ---------------------------------------------------------------- D/E: optical flow
+def _smooth_image(seed, H, W):
+    r = rng(seed)
+    y, x = np.mgrid[0:H, 0:W].astype(np.float32)
+    img = 0.5 + 0.2 * np.sin(x * 0.21 + 0.3 * y * 0.1) + 0.2 * np.cos(y * 0.17) + 0.05 * r.random((H, W), dtype=np.float32)
+    return img.astype(np.float32)
+
+
+def test_WarpingKernel(orc, hip):
+    H, W = 50, 70
+    img = _smooth_image(50, H, W)
+    uv = rng(51).uniform(-6, 6, (H, W, 2)).astype(np.float32)
+    uv[0, 0] = [-30, 200]  # far outside: mirror addressing
+
+    def make():
+        out = np.zeros((H, W + 1), np.float32)
+        return (W, H, pitch_of(out), Tex(uv), out, Tex(img)), [out]
+
+    (o,), (h,) = run_both(orc, hip, "WarpingKernel", make)
+    assert_bitexact(o, h, "WarpingKernel")
+
+
+@pytest.mark.parametrize("rot", [0.0, 0.02])
+def test_CreateFlowFieldFromTiles(orc, hip, rot):
+    H, W, tcx, tcy = 48, 80, 5, 3
+    ts = rng(52).uniform(-3, 3, (tcy, tcx, 2)).astype(np.float32)
+
+    def make():
+        out = np.zeros((H, W, 2), np.float32)
+        return (out, Tex(ts), 16, tcx, tcy, W, H, pitch_of(out), F2([0.5, -1.5] if rot else [0, 0]), rot), [out]
+
+    (o,), (h,) = run_both(orc, hip, "CreateFlowFieldFromTiles", make)
+    if rot == 0.0:
+        assert_bitexact(o, h, "CreateFlowFieldFromTiles")
+    else:  # sinf/cosf: ocml vs glibc, <= 2 ulp on O(50 px) lever arms
+        np.testing.assert_allclose(h, o, atol=2e-5)
+
+
+def test_ComputeDerivatives(orc, hip):
+    H, W = 40, 56
+    a, b = _smooth_image(53, H, W), _smooth_image(54, H, W)
+
+    def make():
+        Ix, Iy, Iz = (np.zeros((H, W), np.float32) for _ in range(3))
+        return (W, H, pitch_of(Ix), Ix, Iy, Iz, Tex(a), Tex(b)), [Ix, Iy, Iz]
+
+    o, h = run_both(orc, hip, "ComputeDerivativesKernel", make)
+    for x, y in zip(o, h):
+        assert_bitexact(x, y, "ComputeDerivativesKernel")
+
+    def make2():
+        Ix, Iy = (np.zeros((H, W), np.float32) for _ in range(2))
+        return (W, H, pitch_of(Ix), Ix, Iy, Tex(a)), [Ix, Iy]
+
+    o, h = run_both(orc, hip, "ComputeDerivatives2Kernel", make2)
+    for x, y in zip(o, h):
+        assert_bitexact(x, y, "ComputeDerivatives2Kernel")
+
+
+@pytest.mark.parametrize("hw", [1, 3])
+def test_lucasKanadeOptim(orc, hip, hw):
+    H, W = 36, 52
+    r = rng(55)
+    fx = (r.random((H, W), dtype=np.float32) - 0.5) * 0.4
+    fy = (r.random((H, W), dtype=np.float32) - 0.5) * 0.4
+    ft = (r.random((H, W), dtype=np.float32) - 0.5) * 0.1
+    fx[10:14, 10:14] = 0
+    fy[10:14, 10:14] = 0       # singular windows -> rejected / zero pseudo-inverse
+    sh0 = r.uniform(-1, 1, (H, W, 2)).astype(np.float32)
+
+    def make():
+        sh = sh0.copy()
+        return (sh, fx, fy, ft, pitch_of(sh), pitch_of(fx), W, H, hw, 1e-3), [sh]
+
+    (o,), (h,) = run_both(orc, hip, "lucasKanadeOptim", make)
+    # atan2f/cosf/sinf differ by <= 2 ulp between ocml and glibc; the update is O(1) px
+    np.testing.assert_allclose(h, o, atol=5e-5, rtol=1e-4)
+    assert_bitexact(o[:hw], sh0[:hw])   # border ring untouched
+
+
+def test_lucasKanadeIterationFused_equals_chain(orc, hip):
+    """Fused D2+D3+D4 == oracle chain Warping -> ComputeDerivatives -> lucasKanadeOptim."""
+    H, W, hw = 70, 100, 3
+    base = _smooth_image(56, H + 8, W + 8)
+    ref = np.ascontiguousarray(base[4:4 + H, 4:4 + W])
+    mov = np.ascontiguousarray(base[3:3 + H, 6:6 + W])
+    flow0 = np.zeros((H, W, 2), np.float32)
+    flow0[..., 0] = -1.6
+    flow0[..., 1] = 0.7
+    flow = flow0.copy()
+    warped = np.zeros((H, W), np.float32)
+    Ix, Iy, Iz = (np.zeros((H, W), np.float32) for _ in range(3))
+    orc.call("WarpingKernel", W, H, pitch_of(warped), Tex(flow), warped, Tex(mov))
+    orc.call("ComputeDerivativesKernel", W, H, pitch_of(Ix), Ix, Iy, Iz, Tex(ref), Tex(warped))
+    orc.call("lucasKanadeOptim", flow, Ix, Iy, Iz, pitch_of(flow), pitch_of(Ix), W, H, hw, 1e-4)
+    out = np.full((H, W, 2), 99, np.float32)
+    hip.call("lucasKanadeIterationFused", flow0, out, pitch_of(out), ref, mov, pitch_of(ref), W, H, hw, 1e-4)
+    # separable window sums + M^-1 * sum(grad*It) instead of sum(M^-1 grad * It): rounding only
+    np.testing.assert_allclose(out, flow, atol=1e-4)
+    assert np.abs(flow - flow0).max() > 0.05   # the iteration did move the flow
+    # true shift is (-2, +1): one iteration gets closer
+    err0 = np.abs(flow0[10:-10, 10:-10] - [-2, 1]).mean()
+    err1 = np.abs(out[10:-10, 10:-10] - [-2, 1]).mean()
+    assert err1 < err0
+
+
+def test_structure_tensor_and_kernel_param(orc, hip):
+    H, W = 44, 60
+    img = _smooth_image(57, H, W)
+    Ix, Iy = (np.zeros((H, W), np.float32) for _ in range(2))
+    orc.call("ComputeDerivatives2Kernel", W, H, pitch_of(Ix), Ix, Iy, Tex(img))
+
+    def make():
+        out = np.zeros((H, W, 3), np.float32)
+        return (Ix, Iy, out, W, H, pitch_of(Ix), pitch_of(out)), [out]
+
+    (o,), (h,) = run_both(orc, hip, "ComputeStructureTensor", make)
+    assert_bitexact(o, h, "ComputeStructureTensor")
+    fused = np.zeros((H, W, 3), np.float32)
+    hip.call("structureTensorFused", img, pitch_of(img), fused, pitch_of(fused), W, H)
+    # direct texel loads instead of bilinear fetches at pixel centres: <= 1e-6 relative blend error
+    np.testing.assert_allclose(fused, o, rtol=1e-4, atol=1e-7)
+
+    def make_k():
+        t = o.copy()
+        t[0, 0] = 0          # lam1+lam2 = 0 -> NaN anisotropy
+        t[0, 1] = [1e-3, 1e-3, 0]  # isotropic: help = 0 -> (c,s) fallback
+        return (t, W, H, pitch_of(t), 0.005, 0.05, 0.3, 2.0, 2.0, 2.0), [t]
+
+    (ok,), (hk,) = run_both(orc, hip, "ComputeKernelParam", make_k)
+    assert_bitexact(ok, hk, "ComputeKernelParam")
+
+
+# ---------------------------------------------------------------- F: robustness
+def test_ComputeRobustnessMask(orc, hip):
+    H, W = 36, 52
+    r = rng(60)
+    ref = r.random((H, W, 3), dtype=np.float32)
+    mov = np.clip(ref + r.normal(0, 0.02, ref.shape).astype(np.float32), 0, 1).astype(np.float32)
+    mov[5:9, 5:9] += 0.5
+    uv = r.uniform(-5, 5, (H, W, 2)).astype(np.float32)
+
+    def make():
+        mask = np.zeros((H, W, 4), np.float32)
+        return (ref, mov, mask, Tex(uv), W, H, pitch_of(ref), pitch_of(mask), 1e-4, 1e-6, 0.8), [mask]
+
+    (o,), (h,) = run_both(orc, hip, "ComputeRobustnessMask", make)
+    # expf: ocml vs glibc (<= 2 ulp of an O(1) value)
+    np.testing.assert_allclose(h, o, atol=1e-6, rtol=1e-6)
+    assert (h[0] == 0).all() and (h[:, -1] == 0).all()  # ring untouched
+    assert h[..., :3].max() > 0.5 and h[..., :3].min() == 0.0
+
+
+# ---------------------------------------------------------------- H / I / glue
+def test_ApplyWeighting_Gamma(orc, hip):
+    H, W = 30, 44
+    r = rng(61)
+    fin = r.random((H, W, 3), dtype=np.float32) * 4
+    wt = r.random((H, W, 3), dtype=np.float32) * 4
+    wt[0, :5] = 0
+    wt[1, :5] = -1          # w + 1 == 0 -> output 0
+    wt[2, :5] = 1e-4        # below threshold -> fallback blended in
+
+    def make():
+        io = r0.copy()
+        return (io, fin, wt, W, H, pitch_of(io), 1e-3), [io]
+
+    r0 = rng(62).random((H, W, 3), dtype=np.float32)
+    (o,), (h,) = run_both(orc, hip, "ApplyWeighting", make)
+    assert_bitexact(o, h, "ApplyWeighting")
+
+    def make_g():
+        io = (o * 1.2 - 0.1).astype(np.float32)
+        io[0, 0] = np.nan
+        return (io, W, H, pitch_of(io)), [io]
+
+    (og,), (hg,) = run_both(orc, hip, "GammasRGB", make_g)
+    np.testing.assert_allclose(hg, og, atol=3e-7, rtol=3e-7)  # powf: ocml vs glibc
+    assert hg[0, 0, 0] == 0.0
+
+
+def test_finishFused_equals_chain(orc, hip):
+    H, W, s = 24, 36, 2
+    hrH, hrW = H * s, W * s
+    r = rng(63)
+    fb = r.random((H, W, 3), dtype=np.float32)
+    fin = r.random((hrH, hrW, 3), dtype=np.float32) * 3
+    wt = r.random((hrH, hrW, 3), dtype=np.float32) * 3
+    wt[:3] = 0
+    io = np.zeros((hrH, hrW, 3), np.float32)
+    orc.call("resampleFloat3", fb, pitch_of(fb), W, H, io, pitch_of(io), hrW, hrH, 0.0, 1.0, 0.0, 1.0)
+    orc.call("ApplyWeighting", io, fin, wt, hrW, hrH, pitch_of(io), 1e-3)
+    lin = io.copy()
+    orc.call("GammasRGB", io, hrW, hrH, pitch_of(io))
+    q = np.zeros((hrH, hrW, 3), np.uint16)
+    orc.call("quantize", io, pitch_of(io), q, None, hrW, hrH, 65535.0)
+    out = np.zeros_like(io)
+    q2 = np.zeros_like(q)
+    hip.call("finishFused", fin, wt, pitch_of(fin), fb, pitch_of(fb), W, H, 0.0, 1.0, 0.0, 1.0, out, pitch_of(out), q2,
+             hrW, hrH, 1e-3, 1, 65535.0)
+    np.testing.assert_allclose(out, io, atol=3e-7, rtol=3e-7)
+    assert np.abs(q2.astype(np.int32) - q.astype(np.int32)).max() <= 1   # +-1 LSB (16 bit)
+    out_lin = np.zeros_like(io)
+    hip.call("finishFused", fin, wt, pitch_of(fin), fb, pitch_of(fb), W, H, 0.0, 1.0, 0.0, 1.0, out_lin, pitch_of(out),
+             None, hrW, hrH, 1e-3, 0, 65535.0)
+    assert_bitexact(lin, out_lin, "finishFused (no gamma)")
+
+
+def test_fourier_helpers(orc, hip):
+    H, W = 32, 48
+    spec = rng(64).random((H, W // 2 + 1, 2), dtype=np.float32)
+    for lp, hp, lps, hps, ca in [(0.3, 0.0, 0.0, 0.0, 0), (0.3, 0.05, 0.05, 0.02, 2), (0.0, 0.0, 0.1, 0.0, 0)]:
+        def make():
+            s = spec.copy()
+            return (s, pitch_of(s), W, H, lp, hp, lps, hps, ca), [s]
+        (o,), (h,) = run_both(orc, hip, "fourierFilter", make)
+        np.testing.assert_allclose(h, o, atol=1e-6, rtol=1e-5)  # expf
+
+    def make_s():
+        s = rng(65).random((H, W, 2), dtype=np.float32)
+        return (s, W, H), [s]
+    (o,), (h,) = run_both(orc, hip, "fftshift", make_s)
+    assert_bitexact(o, h, "fftshift")
+
+    def make_c():
+        a = rng(66).random((100, 2), dtype=np.float32)
+        b = rng(67).random((100, 2), dtype=np.float32)
+        return (a, b, 100), [b]
+    (o,), (h,) = run_both(orc, hip, "conjugateComplexMulKernel", make_c)
+    assert_bitexact(o, h, "conjugateComplexMulKernel")
+
+
+def test_glue_stages(orc, hip):
+    H, W = 34, 50
+    r = rng(70)
+    rgb = r.random((H, W, 3), dtype=np.float32)
+
+    def mk_gray():
+        out = np.zeros((H, W), np.float32)
+        return (rgb, pitch_of(rgb), out, pitch_of(out), W, H), [out]
+    (o,), (h,) = run_both(orc, hip, "rgbToGray", mk_gray)
+    assert_bitexact(o, h, "rgbToGray")
+    gray = o
+    raw = r.integers(0, 4096, (H, W), dtype=np.uint16)
+
+    def mk_u16():
+        out = np.zeros((H, W), np.float32)
+        return (raw, out, pitch_of(out), W, H, 1.0 / 4095.0), [out]
+    (o,), (h,) = run_both(orc, hip, "u16ToFloat", mk_u16)
+    assert_bitexact(o, h, "u16ToFloat")
+    taps = np.zeros(99, np.float32)
+    n = orc.o.gaussin_filter_1D(1.0, taps)
+    for chan, src in [(1, gray), (3, rgb)]:
+        def mk_f():
+            tmp, out = np.zeros_like(src), np.zeros_like(src)
+            return (src, pitch_of(src), tmp, out, pitch_of(out), W, H, chan, Host(taps), n), [out]
+        (o,), (h,) = run_both(orc, hip, "separableFilter", mk_f)
+        assert_bitexact(o, h, f"separableFilter chan={chan}")
+
+    def mk_d():
+        out = np.zeros((H // 2, W // 2), np.float32)
+        return (gray, pitch_of(gray), out, pitch_of(out), W // 2, H // 2), [out]
+    (o,), (h,) = run_both(orc, hip, "downsample2x", mk_d)
+    assert_bitexact(o, h, "downsample2x")
+    fl = r.uniform(-3, 3, (H, W, 2)).astype(np.float32)
+
+    def mk_s():
+        f = fl.copy()
+        return (f, pitch_of(f), W, H, 2.0), [f]
+    (o,), (h,) = run_both(orc, hip, "scaleFlow", mk_s)
+    assert_bitexact(o, h, "scaleFlow")
+
+    def mk_4():
+        out = np.ones((H, W, 4), np.float32)
+        return (rgb, pitch_of(rgb), out, pitch_of(out), W, H), [out]
+    (o,), (h,) = run_both(orc, hip, "float3ToFloat4", mk_4)
+    assert_bitexact(o, h, "float3ToFloat4")
+
+    def mk_r():
+        out = np.zeros((H * 3, W * 3, 3), np.float32)
+        return (rgb, pitch_of(rgb), W, H, out, pitch_of(out), W * 3, H * 3, 0.25, 0.75, 0.1, 0.9), [out]
+    (o,), (h,) = run_both(orc, hip, "resampleFloat3", mk_r)
+    assert_bitexact(o, h, "resampleFloat3")
+    img8 = r.integers(0, 256, (H, W, 3), dtype=np.uint8)
+
+    def mk_sh():
+        out = np.full((H, W, 3), 9, np.uint8)
+        return (img8, out, H, W, 3, W * 3, W * 3), [out]
+    (o,), (h,) = run_both(orc, hip, "sharpenImg2", mk_sh)
+    np.testing.assert_array_equal(o, h)
+
+
+def test_gaussin_filter_1D_host(orc, hip):
+    import ctypes
+    for sigma in [0.0, 0.5, 1.0, 2.7, 100.0]:
+        t1 = np.zeros(99, np.float32)
+        n1 = orc.o.gaussin_filter_1D(sigma, t1)
+        t2 = (ctypes.c_float * 99)()
+        n2 = hip.L.gaussin_filter_1D(sigma, t2)
+        assert n1 == n2
+        np.testing.assert_array_equal(t1[:n1], np.array(t2[:n2], np.float32))
