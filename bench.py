@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MFSR hot path on MI355X.
+
+Metric (BASELINE.json): Mpix/s end-to-end, N-frame burst -> x2 super-resolved
+frame.  One "step" = one whole burst through the hot path (reference products,
+per-frame align -> robustness -> warp+fuse, exchange, finish), inputs already
+resident in HBM.  Workload at N=1 = BASELINE configs[2]: 16 frames of 3840x2160
+RGGB u16, x2 (the configuration north_star quotes its roofline target on).
+
+Multi-GPU: weak scaling over the burst dimension -- every rank aligns and fuses
+FRAMES_PER_GPU frames of ONE burst of FRAMES_PER_GPU*N frames into its private
+HR accumulators; the accumulators are summed with an RCCL reduce-scatter over
+xGMI, each rank finishes its stripe, rank 0 gathers the u16 result
+(multi_frame_super_resolution_amd/distributed.py).  `--strong` keeps the burst
+at 16 frames and shards it instead.
+
+Also reported on the same JSON line:
+  roofline     : the warp+fuse kernel (accumulateSuperResFull), HIP-event timed
+                 around every launch inside the timed region, vs the 8 TB/s HBM peak;
+  cpu_baseline : the CPU oracle pipeline ("port" of the same algorithm; the
+                 reference's own CPU path is third-party OpenCV BTVL1, absent here)
+                 timed on the host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (width, height, frames_per_gpu, scale, mono)
+    "4k16_rggb_x2": (3840, 2160, 16, 2, False),      # BASELINE configs[2]
+    "1080p5_gray_x2": (1920, 1080, 5, 2, True),      # BASELINE configs[1]
+    "4k16_rggb_x4": (3840, 2160, 16, 4, False),      # BASELINE configs[3] (per GPU)
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def fuse_bytes_per_launch(W, H, s, mono):
+    """ALGORITHMIC bytes of one accumulate launch (one frame), reference structure
+    (accumulators read-modify-written in HBM): HR*48 B for imgOut/totalWeights
+    (2 x float3 read + write) + the per-frame inputs at their stored resolution:
+    raw u16 (LR*2) + flow float2 + kernel-param float4 + certainty float4."""
+    lr, hr = W * H, W * H * s * s
+    trk = lr if mono else lr // 4          # flow / kernel-param field resolution
+    return hr * 48 + lr * 2 + trk * (8 + 16) + (lr // 4) * 16
+
+
+def cpu_baseline(W, H, s, mono, sample_frames, seed):
+    """Oracle pipeline on the host cores, bounded sample: `sample_frames` frames
+    (1 reference + the rest moved) of the same frame size."""
+    import numpy as np
+    from multi_frame_super_resolution_amd.pipeline import default_config
+    from multi_frame_super_resolution_amd.synth import make_burst
+    from oracle.bindings import oracle
+    from oracle.pipeline import OraclePipeline
+
+    frames, _, _ = make_burst(W, H, sample_frames, scale=s, mono=mono, seed=seed, device="cpu")
+    nf = [f.numpy().view(np.uint16) for f in frames]
+    cfg = default_config(W, H, sample_frames, s, mono)
+    op = OraclePipeline(cfg)
+    t0 = time.perf_counter()
+    op.process(nf)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(sample_frames * W * H / dt / 1e6, 3),
+        "unit": "Mpix/s",
+        "cores": int(oracle().num_threads()),
+        "kind": "port",
+        "sample": f"{sample_frames} frames of {W}x{H} (1 reference + {sample_frames - 1} moved), x{s}, "
+                  f"whole pipeline, OpenMP, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="4k16_rggb_x2", choices=list(WORKLOADS))
+    ap.add_argument("--strong", action="store_true", help="fixed 16-frame burst sharded over the GPUs")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "reduce", "reduce_scatter"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=4)
+    ap.add_argument("--unfused", action="store_true", help="one launch per reference kernel (A/B against the fused path)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from multi_frame_super_resolution_amd import distributed as mdist
+    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, default_config
+    from multi_frame_super_resolution_amd.synth import make_burst
+
+    W, H, fpg, s, mono = WORKLOADS[args.workload]
+    n_frames = fpg if args.strong else fpg * world
+    cfg = default_config(W, H, n_frames, s, mono)
+    cfg.fused = 0 if args.unfused else 1
+    pipe = BurstPipeline(cfg, dev)
+
+    # synthetic burst: one scene (same seed on every rank), this rank's frames only
+    seed = 1234 + 2
+    mine = mdist.frames_of_rank(n_frames, rank, world)
+    ref_frames, _, _ = make_burst(W, H, 1, scale=s, mono=mono, seed=seed, device=dev)
+    shard, _, _ = make_burst(W, H, len(mine), scale=s, mono=mono, seed=seed, device=dev, shift_seed=seed + 100 + rank,
+                             first_is_reference=False)
+    frames = {k: shard[i] for i, k in enumerate(mine)}
+    frames[cfg.reference] = ref_frames[0]
+    del shard
+    torch.cuda.synchronize()
+
+    def step():
+        if world > 1:
+            mdist.accumulate_local(pipe, frames, rank, world, n_frames)
+            return mdist.exchange_and_finish(pipe, args.exchange)
+        return mdist.process_burst(pipe, frames, n_frames=n_frames)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    pipe.L.burst_timing(pipe._h, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tot_ms, launches = ctypes.c_double(0), ctypes.c_int(0)
+    pipe.L.burst_timing_read(pipe._h, ctypes.byref(tot_ms), ctypes.byref(launches))
+    pipe.L.burst_timing(pipe._h, 0)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = n_frames * W * H * args.steps / dt / 1e6
+        bytes_launch = fuse_bytes_per_launch(W, H, s, mono)
+        k_ms = tot_ms.value / max(launches.value, 1)
+        achieved = bytes_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "fuse_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mpix/s end-to-end (N-frame burst -> x2 SR)" if s == 2 else f"Mpix/s end-to-end (N-frame burst -> x{s} SR)",
+            "value": round(value, 2),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong" if args.strong else "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n_frames}-frame {W}x{H} {'gray' if mono else 'RGGB u16'} burst -> x{s} "
+                            f"({args.workload}; BASELINE configs[{ {'4k16_rggb_x2': 2, '1080p5_gray_x2': 1, '4k16_rggb_x4': 3}[args.workload] }])",
+                "frames_per_gpu": len(mine),
+                "burst_frames": n_frames,
+                "output_mpix_per_s": round(s * s * W * H * args.steps / dt / 1e6, 2),
+                "parallelism": "1 GPU" if world == 1 else f"frame-shard x{world} + RCCL {args.exchange} of HR accumulators",
+                "kernels": "unfused (one launch per reference kernel)" if args.unfused else "fused",
+            },
+            "roofline": {
+                "kernel": "k_accumulateSuperRes<GEOM_FULL,fast> (warp+fuse, one launch per frame)",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": traffic,
+                "bytes_per_launch": bytes_launch,
+                "avg_launch_ms": round(k_ms, 4),
+                "launches_timed": launches.value,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(W, H, s, mono, args.cpu_sample_frames, seed)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    pipe.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

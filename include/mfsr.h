@@ -328,6 +328,16 @@ int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mf
  * out16 dense interleaved u16 HR (may be NULL). */
 int mfsr_burst_finish(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights, mfsr_float3* outImg,
                       uint16_t* out16, mfsr_stream_t stream);
+/* finish restricted to HR rows [row0, row0+rows) (pointers are those of the
+ * full images): each rank of a reduce-scattered burst normalises its stripe.
+ * Fused kernels only. */
+int mfsr_burst_finish_rows(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights,
+                           mfsr_float3* outImg, uint16_t* out16, int row0, int rows, mfsr_stream_t stream);
+/* HIP-event timing of the warp+fuse (accumulate) launches made by add_frame on
+ * the caller's stream: timing(b,1) starts a series, timing_read synchronises with
+ * the events and returns the summed kernel milliseconds and the launch count. */
+int mfsr_burst_timing(mfsr_burst* b, int enable);
+int mfsr_burst_timing_read(mfsr_burst* b, double* totalMs, int* launches);
 /* last per-frame flow field (tracking resolution, raw-pixel units) and mask,
  * for tests: returns device pointers valid until the next add_frame */
 int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2d* mask, mfsr_tex2d* kernelParam,

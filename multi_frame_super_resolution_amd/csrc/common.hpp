@@ -67,7 +67,7 @@ struct __attribute__((packed, aligned(4))) pix3 {
     float x, y, z;
 };
 
-// float -> int: v_cvt_i32_f32 (NaN -> 0, saturating), same as the oracle's orc_f2i
+// float -> int: v_cvt_i32_f32 (NaN -> 0, saturating), the CPU oracle converts the same way
 __device__ __forceinline__ int f2i(float f) { return __float2int_rz(f); }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }

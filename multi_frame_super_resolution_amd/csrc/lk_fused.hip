@@ -20,6 +20,11 @@
 // summation order the flow update agrees with the three-kernel chain to fp32
 // rounding (tests: |d flow| <= 1e-4 px), not bit for bit.
 //
+// Argument order of the derivative stage: texSource = warped moved frame,
+// texTarget = reference.  The reference's 5-point stencil (:116-119) is MINUS the
+// usual derivative and Iz = source - target (:131); only with this order does
+// `shift += UV` (:322-323) descend on |ref(p) - moved(p+u)|.
+//
 // Flow is double-buffered (shiftsIn -> shiftsOut): the halo of a tile reads
 // flow values owned by other workgroups, so an in-place update would race.
 #include "common.hpp"
@@ -87,8 +92,8 @@ __global__ void __launch_bounds__(LK_THREADS)
         t1 += w[-1] * 8.0f;
         t1 -= w[-2];
         t1 /= 12.0f;
-        const float Ix = (t0 + t1) * 0.5f;
-        const float It = r[0] - w[0];
+        const float Ix = (t1 + t0) * 0.5f;  // source = warped, target = reference (see header note)
+        const float It = w[0] - r[0];       // Iz = source - target (opticalFlow.cu:131)
         t0 = r[2 * BW];
         t0 -= r[BW] * 8.0f;
         t0 += r[-BW] * 8.0f;
@@ -99,7 +104,7 @@ __global__ void __launch_bounds__(LK_THREADS)
         t1 += w[-BW] * 8.0f;
         t1 -= w[-2 * BW];
         t1 /= 12.0f;
-        const float Iy = (t0 + t1) * 0.5f;
+        const float Iy = (t1 + t0) * 0.5f;
         s_p[i] = Ix * Ix;
         s_p[planeA + i] = Ix * Iy;
         s_p[2 * planeA + i] = Iy * Iy;

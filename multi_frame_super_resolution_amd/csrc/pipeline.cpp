@@ -32,6 +32,7 @@
 namespace {
 
 constexpr int kMaxLevels = 4;
+constexpr int kMaxTimedLaunches = 4096;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -198,6 +199,10 @@ struct mfsr_burst {
     int ntensorTaps;
     Img* flowCur;  // flow of the last add_frame (raw-pixel units)
     bool haveRef;
+    // optional per-launch timing of the accumulate kernel (bench.py roofline leg)
+    bool timing;
+    int nEvents;
+    hipEvent_t evStart[kMaxTimedLaunches], evStop[kMaxTimedLaunches];
 };
 
 #define TRY(expr)                  \
@@ -294,11 +299,51 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     b->ntensorTaps = mfsr_gaussin_filter_1D(cfg->sigmaTensor, b->tensorTaps);
     b->flowCur = &b->L.flowA;
     b->haveRef = false;
+    b->timing = false;
+    b->nEvents = 0;
+    memset(b->evStart, 0, sizeof(b->evStart));
+    memset(b->evStop, 0, sizeof(b->evStop));
     *out = b;
     return MFSR_OK;
 }
 
-extern "C" void mfsr_burst_destroy(mfsr_burst* b) { delete b; }
+extern "C" void mfsr_burst_destroy(mfsr_burst* b)
+{
+    if (!b) return;
+    for (int i = 0; i < kMaxTimedLaunches; i++) {
+        if (b->evStart[i]) (void)hipEventDestroy(b->evStart[i]);
+        if (b->evStop[i]) (void)hipEventDestroy(b->evStop[i]);
+    }
+    delete b;
+}
+
+// Per-launch timing of the warp+fuse (accumulate) kernel with HIP events recorded
+// on the caller's stream around each launch.  enable != 0 starts a fresh series.
+extern "C" int mfsr_burst_timing(mfsr_burst* b, int enable)
+{
+    MFSR_REQUIRE(b != nullptr);
+    b->timing = enable != 0;
+    b->nEvents = 0;
+    return MFSR_OK;
+}
+
+// Synchronises with the recorded events and returns the summed kernel time and
+// the number of timed launches since mfsr_burst_timing(b, 1).
+extern "C" int mfsr_burst_timing_read(mfsr_burst* b, double* totalMs, int* launches)
+{
+    MFSR_REQUIRE(b && totalMs && launches);
+    double total = 0;
+    for (int i = 0; i < b->nEvents; i++) {
+        MFSR_HIP_TRY(hipEventSynchronize(b->evStop[i]));
+        float ms = 0;
+        MFSR_HIP_TRY(hipEventElapsedTime(&ms, b->evStart[i], b->evStop[i]));
+        total += ms;
+    }
+    *totalMs = total;
+    *launches = b->nEvents;
+    b->nEvents = 0;
+    return MFSR_OK;
+}
 
 // A1 + tracking pyramid for one frame (shared by reference and moved frames)
 static int prepare_frame(mfsr_burst* b, const uint16_t* raw, Img& half, Img* pyr, mfsr_stream_t stream)
@@ -444,8 +489,11 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
             } else {
                 TRY(mfsr_WarpingKernel(L.tw, L.th, L.warped.pitch, as_tex(*flow), (float*)L.warped.ptr, as_tex(L.movPyr[0]),
                                        stream));
+                // texSource = warped moved frame, texTarget = reference: the reference's stencil is
+                // minus the usual derivative (opticalFlow.cu:116-119) and Iz = source - target (:131),
+                // so this is the order for which `shift += UV` (:322-323) descends.
                 TRY(mfsr_ComputeDerivativesKernel(L.tw, L.th, L.Ix.pitch, (float*)L.Ix.ptr, (float*)L.Iy.ptr,
-                                                  (float*)L.It.ptr, as_tex(L.refPyr[0]), as_tex(L.warped), stream));
+                                                  (float*)L.It.ptr, as_tex(L.warped), as_tex(L.refPyr[0]), stream));
                 TRY(mfsr_lucasKanadeOptim((mfsr_float2*)flow->ptr, (const float*)L.Ix.ptr, (const float*)L.Iy.ptr,
                                           (const float*)L.It.ptr, flow->pitch, L.Ix.pitch, L.tw, L.th, c.lkHalfWindow,
                                           c.lkMinDet, stream));
@@ -461,8 +509,19 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
     }
     b->flowCur = flow;
     // G: accumulate onto the HR grid
+    const bool timed = b->timing && b->nEvents < kMaxTimedLaunches;
+    if (timed) {
+        const int i = b->nEvents;
+        if (!b->evStart[i]) MFSR_HIP_TRY(hipEventCreate(&b->evStart[i]));
+        if (!b->evStop[i]) MFSR_HIP_TRY(hipEventCreate(&b->evStop[i]));
+        MFSR_HIP_TRY(hipEventRecord(b->evStart[i], mfsr_s(stream)));
+    }
     TRY(mfsr_accumulateSuperResFull(raw, imgOut, totalWeights, (const mfsr_float4*)L.mask.ptr, as_tex(L.kparam4),
                                     as_tex(*flow), white, black, L.W, L.H, c.scale, strideOut, L.mask.pitch, stream));
+    if (timed) {
+        MFSR_HIP_TRY(hipEventRecord(b->evStop[b->nEvents], mfsr_s(stream)));
+        b->nEvents++;
+    }
     return MFSR_OK;
 }
 
@@ -486,6 +545,28 @@ extern "C" int mfsr_burst_finish(mfsr_burst* b, const mfsr_float3* imgOut, const
     if (c.applyGamma) TRY(mfsr_GammasRGB(outImg, L.hrW, L.hrH, pitch, stream));
     if (out16) TRY(mfsr_quantize(outImg, pitch, out16, nullptr, L.hrW, L.hrH, 65535.0f, stream));
     return MFSR_OK;
+}
+
+// finish on the HR row stripe [row0, row0+rows): used after a reduce-scatter of
+// the accumulators, where each rank normalises only its own stripe.  Pointers are
+// those of the FULL images; only the stripe is read/written.
+extern "C" int mfsr_burst_finish_rows(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights,
+                                      mfsr_float3* outImg, uint16_t* out16, int row0, int rows, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && imgOut && totalWeights && (outImg || out16));
+    MFSR_REQUIRE(b->haveRef);
+    const mfsr_config& c = b->cfg;
+    Layout& L = b->L;
+    MFSR_REQUIRE(row0 >= 0 && rows > 0 && row0 + rows <= L.hrH);
+    const int pitch = 12 * L.hrW;
+    const float v0 = (float)row0 / (float)L.hrH, v1 = (float)(row0 + rows) / (float)L.hrH;
+    const size_t off = (size_t)row0 * pitch;
+    return mfsr_finishFused((const mfsr_float3*)((const char*)imgOut + off),
+                            (const mfsr_float3*)((const char*)totalWeights + off), pitch,
+                            (const mfsr_float3*)L.fallback.ptr, L.fallback.pitch, L.W, L.H, 0.0f, 1.0f, v0, v1,
+                            outImg ? (mfsr_float3*)((char*)outImg + off) : nullptr, pitch,
+                            out16 ? out16 + (size_t)row0 * L.hrW * 3 : nullptr, L.hrW, rows, c.weightThreshold,
+                            c.applyGamma, 65535.0f, stream);
 }
 
 extern "C" int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2d* mask, mfsr_tex2d* kernelParam,

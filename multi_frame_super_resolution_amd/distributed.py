@@ -1,0 +1,116 @@
+"""Frame-sharded multi-GPU burst processing: one process per GPU, RCCL over xGMI.
+
+SURVEY.md section 8e: the burst (frame) dimension shards naturally.  Stages D
+(flow), F (robustness) and G (accumulate) are independent per moved frame given
+the reference-frame products, which every rank computes redundantly (they are
+LR-sized); ``imgOut`` / ``totalWeights`` are plain sums over frames
+(reference DeBayerKernels.cu:440-441,374-375), so the only exchange step is a
+sum of the HR accumulators.  The reference itself is single-GPU
+(``cudaSetDevice(0)``, kernel.cu:45): this module is new work.
+
+Two exchange modes:
+
+``reduce``          ``reduce(sum)`` of both accumulators onto rank 0, which then
+                    runs the finish stage on the whole HR grid (what north_star
+                    describes).  Root-bound: every peer sends the full 2 x HR x 12 B
+                    over its one xGMI link to rank 0.
+``reduce_scatter``  (default when the HR rows divide evenly) every rank receives
+                    1/world of the HR rows summed over all ranks, finishes its own
+                    stripe, and rank 0 gathers the 6 B/px u16 result.  All 7 xGMI
+                    links of every GPU carry traffic at once instead of funnelling
+                    through the root's.
+
+Summation order differs from the sequential single-GPU loop, so results agree
+with it to fp32 rounding (inside the +-1 LSB output budget), not bit for bit.
+
+The functions are written against a small duck-typed "pipe" interface
+(``cfg``, ``img_out``, ``total_weights``, ``reset_accumulators``,
+``set_reference``, ``add_frame``, ``finish``, ``finish_rows``) so that the
+world_size-2 gloo tests can drive them with a CPU stand-in.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def frames_of_rank(n_frames: int, rank: int, world: int) -> List[int]:
+    """Round-robin frame shard: rank g owns frames {k : k mod world == g}."""
+    return [k for k in range(n_frames) if k % world == rank]
+
+
+def accumulate_local(pipe, frames, rank: int, world: int, n_frames: Optional[int] = None) -> List[int]:
+    """Reference products (replicated) + this rank's frame shard into the local accumulators.
+
+    ``frames`` is indexable by global frame number: a list of all frames, or a
+    mapping that holds only this rank's shard plus the reference frame (what a
+    rank of a large burst keeps resident)."""
+    ref = pipe.cfg.reference
+    n = len(frames) if n_frames is None else n_frames
+    pipe.reset_accumulators()
+    pipe.set_reference(frames[ref])
+    mine = frames_of_rank(n, rank, world)
+    for k in mine:
+        pipe.add_frame(frames[k], k == ref)
+    return mine
+
+
+def exchange_and_finish(pipe, mode: str = "auto", group=None):
+    """Sum the HR accumulators over ranks and finish.  Returns the u16 HR image on
+    rank 0 (None elsewhere)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    hr_h = pipe.img_out.shape[0]
+    if mode == "auto":
+        mode = "reduce_scatter" if (world > 1 and hr_h % world == 0) else "reduce"
+    if world == 1:
+        _, out16 = pipe.finish(want_float=False, want_u16=True)
+        return out16
+    if mode == "reduce":
+        dist.reduce(pipe.img_out, dst=0, op=dist.ReduceOp.SUM, group=group)
+        dist.reduce(pipe.total_weights, dst=0, op=dist.ReduceOp.SUM, group=group)
+        if rank == 0:
+            _, out16 = pipe.finish(want_float=False, want_u16=True)
+            return out16
+        return None
+    if mode != "reduce_scatter":
+        raise ValueError(f"unknown exchange mode {mode!r}")
+    rows = hr_h // world
+    row0 = rank * rows
+    # in-place reduce-scatter: rank r's output is rows [r*rows, (r+1)*rows) of its own accumulator
+    _reduce_scatter_rows(pipe.img_out, rows, rank, world, group)
+    _reduce_scatter_rows(pipe.total_weights, rows, rank, world, group)
+    out16 = pipe.finish_rows(row0, rows)  # full-size u16 buffer, stripe filled
+    stripe = out16[row0:row0 + rows]
+    if rank == 0:
+        parts = [out16[r * rows:(r + 1) * rows] for r in range(world)]
+        dist.gather(stripe, gather_list=parts, dst=0, group=group)
+        return out16
+    dist.gather(stripe, gather_list=None, dst=0, group=group)
+    return None
+
+
+def _reduce_scatter_rows(acc: torch.Tensor, rows: int, rank: int, world: int, group):
+    flat = acc.view(-1)
+    chunk = flat.numel() // world
+    out = flat[rank * chunk:(rank + 1) * chunk]
+    if dist.get_backend(group) == "gloo":
+        # gloo has no reduce_scatter: emulate with per-chunk reduces (CPU tests only)
+        for r in range(world):
+            dist.reduce(flat[r * chunk:(r + 1) * chunk], dst=r, op=dist.ReduceOp.SUM, group=group)
+        return
+    tmp = torch.empty_like(out)
+    dist.reduce_scatter_tensor(tmp, flat, op=dist.ReduceOp.SUM, group=group)
+    out.copy_(tmp)
+
+
+def process_burst(pipe, frames, mode: str = "auto", group=None, n_frames: Optional[int] = None):
+    """Whole burst, frame-sharded over the ranks of ``group``; u16 HR image on rank 0."""
+    if not dist.is_initialized():
+        accumulate_local(pipe, frames, 0, 1, n_frames)
+        _, out16 = pipe.finish(want_float=False, want_u16=True)
+        return out16
+    accumulate_local(pipe, frames, dist.get_rank(group), dist.get_world_size(group), n_frames)
+    return exchange_and_finish(pipe, mode, group)

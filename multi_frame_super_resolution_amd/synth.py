@@ -14,7 +14,7 @@ is part of the measured path.
 from __future__ import annotations
 
 import math
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -57,16 +57,24 @@ def _shifted(scene: torch.Tensor, tx: float, ty: float) -> torch.Tensor:
 
 def make_burst(width: int, height: int, frames: int, scale: int = 2, mono: bool = False, seed: int = 1234,
                device="cpu", max_shift: float = 5.0, noise: bool = True, alpha: float = 1e-4, beta: float = 1e-6,
-               black: float = 256.0, white: float = 4095.0 - 256.0) -> Tuple[List[torch.Tensor], torch.Tensor, torch.Tensor]:
-    """Returns (raw frames [H,W] int16 holding u16 bit patterns, shifts [N,2] in LR px, ground truth [3,sH,sW])."""
+               black: float = 256.0, white: float = 4095.0 - 256.0, shift_seed: Optional[int] = None,
+               first_is_reference: bool = True) -> Tuple[List[torch.Tensor], torch.Tensor, torch.Tensor]:
+    """Returns (raw frames [H,W] int16 holding u16 bit patterns, shifts [N,2] in LR px, ground truth [3,sH,sW]).
+
+    ``seed`` fixes the scene; ``shift_seed`` (default: same stream) fixes the per-frame shifts and
+    noise, so ranks of a sharded burst can draw different frames of the SAME scene."""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     s = scale
     m = 32 * s
     hr_h, hr_w = s * height + 2 * m, s * width + 2 * m
     scene = _scene(hr_h, hr_w, gen, device)
+    if shift_seed is not None:
+        gen = torch.Generator(device=device)
+        gen.manual_seed(shift_seed)
     shifts = (torch.rand(frames, 2, generator=gen, device=device) * 2 - 1) * max_shift
-    shifts[0] = 0
+    if first_is_reference:
+        shifts[0] = 0
     out = []
     yy, xx = torch.meshgrid(torch.arange(height, device=device), torch.arange(width, device=device), indexing="ij")
     cfa_idx = ((yy % 2) + (xx % 2))  # RGGB: (0,0)->R=0, (0,1)/(1,0)->G=1, (1,1)->B=2

@@ -8,6 +8,19 @@
  * specified in DESIGN.md ("Pipeline glue") and mirrored 1:1 by the HIP path.
  */
 #include "oracle_common.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* number of host threads the oracle loops use (cpu_baseline.cores in bench.py) */
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 /* J1: gaussin_filter_1D, test_opencv/main.cpp:370-391.  Returns the tap count
  * (<= 99); taps must hold 99 floats. */

@@ -149,8 +149,12 @@ class OraclePipeline:
             for _ in range(c.lkIterations):
                 o.WarpingKernel(self.tw, self.th, _pitch(warped), flow, _pitch(flow), self.tw, self.th, warped, mov0,
                                 _pitch(mov0), self.tw, self.th)
-                o.ComputeDerivativesKernel(self.tw, self.th, _pitch(Ix), Ix, Iy, It, ref0, _pitch(ref0), self.tw, self.th,
-                                           warped, _pitch(warped), self.tw, self.th)
+                # texSource = warped moved frame, texTarget = reference: with the reference's
+                # derivative sign (opticalFlow.cu:116-119 is MINUS the usual 5-point stencil) and
+                # Iz = source - target (:131) this is the argument order for which
+                # `shift += UV` (:322-323) descends; the other order diverges.
+                o.ComputeDerivativesKernel(self.tw, self.th, _pitch(Ix), Ix, Iy, It, warped, _pitch(warped), self.tw,
+                                           self.th, ref0, _pitch(ref0), self.tw, self.th)
                 o.lucasKanadeOptim(flow, Ix, Iy, It, _pitch(flow), _pitch(Ix), self.tw, self.th, c.lkHalfWindow,
                                    float(c.lkMinDet))
             if self.flow_scale != 1:
