@@ -241,8 +241,10 @@ int mfsr_resampleFloat3(const mfsr_float3* in, int inPitch, int inW, int inH, mf
 int mfsr_quantize(const mfsr_float3* in, int inPitch, uint16_t* out16, uint8_t* out8, int width, int height,
                   float maxOut, mfsr_stream_t stream);
 int mfsr_fill_f32(float* dst, size_t count, float value, mfsr_stream_t stream);
-/* test hook for the accumulate kernels: 1 (default) evaluates exp(-w/2) with
- * v_exp_f32, 0 with the ocml expf (tight parity against the oracle). */
+/* variant selector of the accumulate kernels (tests, A/B benchmarks):
+ * 0 = straight kernel, exp(-w/2) with the ocml expf (tight parity against the oracle);
+ * 1 = straight kernel, v_exp_f32; 2 (default) = additionally the restructured x2
+ * strip kernel where it applies (scale 2, Bayer/mono CFA, 16-byte aligned accumulators). */
 int mfsr_set_accumulate_fast_exp(int enable);
 
 /* ---- fused MI355X kernels (same results as the chains they replace, within

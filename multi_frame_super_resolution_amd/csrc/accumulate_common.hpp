@@ -1,0 +1,143 @@
+// accumulate_common.hpp -- tap arithmetic shared by the accumulate kernels
+// (reference test_opencv/DeBayerKernels.cu:288-468).
+#pragma once
+#include "common.hpp"
+
+struct Levels3 {
+    float white[3], black[3];
+};
+
+static inline Levels3 make_levels(mfsr_float3 white, mfsr_float3 black)
+{
+    Levels3 l;
+    l.white[0] = white.x;
+    l.white[1] = white.y;
+    l.white[2] = white.z;
+    l.black[0] = black.x;
+    l.black[1] = black.y;
+    l.black[2] = black.z;
+    return l;
+}
+
+template <bool FAST>
+__device__ __forceinline__ float tap_weight(int px, int py, float kx, float ky, float kz)
+{
+    // DeBayerKernels.cu:335-338 / :427-430
+    float w = (float)(px * px) * kx + (float)(2 * px * py) * kz + (float)(py * py) * ky;
+    if (FAST) {
+        const float t = w * -0.72134752044448170368f;  // -0.5 * log2(e)
+        w = __builtin_amdgcn_exp2f(t);
+    } else {
+        w = expf(-0.5f * w);
+    }
+    if (!finitef(w)) w = (px * py == 0) ? 1.0f : 0.0f;
+    return w;
+}
+
+__device__ __forceinline__ void tap_accumulate(float raw, float w, int color, const float4& cert4, const Levels3& lv,
+                                               pix3& pixel, pix3& totalWeight)
+{
+    // DeBayerKernels.cu:342-370 / :434-462
+    if (color == MFSR_GREEN) {
+        raw = (raw - lv.black[1]) / lv.white[1];
+        float certainty = cert4.y;
+        if (!finitef(certainty)) certainty = 0.0f;
+        pixel.y += raw * w * certainty;
+        totalWeight.y += w * certainty;
+    } else if (color == MFSR_RED) {
+        raw = (raw - lv.black[0]) / lv.white[0];
+        float certainty = cert4.x;
+        if (!finitef(certainty)) certainty = 0.0f;
+        pixel.x += raw * w * certainty;
+        totalWeight.x += w * certainty;
+    } else if (color == MFSR_BLUE) {
+        raw = (raw - lv.black[2]) / lv.white[2];
+        float certainty = cert4.z;
+        if (!finitef(certainty)) certainty = 0.0f;
+        pixel.z += raw * w * certainty;
+        totalWeight.z += w * certainty;
+    }
+}
+
+
+// GEOM_CROP: the reference geometry (x2, output grid dimX x dimY over the central
+//            half of the frame).
+// GEOM_FULL: scale s, output grid (s*dimX) x (s*dimY) over the whole frame.
+enum { GEOM_CROP = 0, GEOM_FULL = 1 };
+
+__device__ __forceinline__ int floordiv_pos(int a, int s)
+{
+    // floor(a / s) for s > 0 and any a
+    int q = a / s;
+    return (a % s < 0) ? q - 1 : q;
+}
+
+// One output pixel of accumulateImagesSuperRes (:379-468) / its full-frame
+// generalisation, straight from the reference: read-modify-write of imgOut and
+// totalWeights at (x, y).  Caller guarantees 1 <= x < outW-1, 1 <= y < outH-1.
+template <int GEOM, bool FAST>
+__device__ __forceinline__ void accumulate_pixel_generic(int x, int y, const uint16_t* __restrict__ dataIn,
+                                                         pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
+                                                         const float4* __restrict__ certaintyMask,
+                                                         const mfsr_tex2d& kernelParam, const mfsr_tex2d& shifts,
+                                                         const Levels3& lv, int dimX, int dimY, int scale, int strideOut,
+                                                         int strideMask, int cfa)
+{
+    const int outW = (GEOM == GEOM_CROP) ? dimX : dimX * scale;
+    const int outH = (GEOM == GEOM_CROP) ? dimY : dimY * scale;
+    pix3 pixel = row_ptr(imgOut, strideOut, y)[x];
+    pix3 totalWeight = row_ptr(totalWeights, strideOut, y)[x];
+
+    float posX, posY, fscale;
+    if (GEOM == GEOM_CROP) {
+        posX = ((float)x + 0.5f + (float)(dimX / 2)) / 2.0f / (float)dimX;  // :398
+        posY = ((float)y + 0.5f + (float)(dimY / 2)) / 2.0f / (float)dimY;
+        fscale = 2.0f;
+    } else {
+        posX = ((float)x + 0.5f) / (float)outW;
+        posY = ((float)y + 0.5f) / (float)outH;
+        fscale = (float)scale;
+    }
+    const float4 kernel = tex4<ADDR_CLAMP>(kernelParam, posX, posY);
+    const float2 shift = tex2<ADDR_CLAMP>(shifts, posX, posY);
+    const int sx = f2i(roundf(shift.x * fscale));  // :403-406
+    const int sy = f2i(roundf(shift.y * fscale));
+
+    int ppsxA[5], ppxA[5];
+#pragma unroll
+    for (int px = -2; px <= 2; px++) {
+        if (GEOM == GEOM_CROP) {
+            ppsxA[px + 2] = clampi((x + px + sx + dimX / 2) / 2, dimX / 4, dimX / 2 - 1 + dimX / 4);  // :419
+            ppxA[px + 2] = clampi((x + px + dimX / 2) / 2, dimX / 4, dimX / 2 - 1 + dimX / 4);        // :422
+        } else {
+            ppsxA[px + 2] = clampi(floordiv_pos(x + px + sx, scale), 0, dimX - 1);
+            ppxA[px + 2] = clampi(floordiv_pos(x + px, scale), 0, dimX - 1);
+        }
+    }
+#pragma unroll
+    for (int py = -2; py <= 2; py++) {
+        int ppsy, ppy;
+        if (GEOM == GEOM_CROP) {
+            ppsy = clampi((y + py + sy + dimY / 2) / 2, dimY / 4, dimY / 2 - 1 + dimY / 4);
+            ppy = clampi((y + py + dimY / 2) / 2, dimY / 4, dimY / 2 - 1 + dimY / 4);
+        } else {
+            ppsy = clampi(floordiv_pos(y + py + sy, scale), 0, dimY - 1);
+            ppy = clampi(floordiv_pos(y + py, scale), 0, dimY - 1);
+        }
+        const uint16_t* rawRow = dataIn + (size_t)ppsy * dimX;
+        const float4* maskRow = row_ptr(certaintyMask, strideMask, ppy / 2);
+#pragma unroll
+        for (int px = -2; px <= 2; px++) {
+            const int ppsx = ppsxA[px + 2];
+            const int color = cfa_at(cfa, ppsy, ppsx);
+            const float w = tap_weight<FAST>(px, py, kernel.x, kernel.y, kernel.z);
+            const float raw = (float)rawRow[ppsx];
+            const float4 cert4 = maskRow[ppxA[px + 2] / 2];
+            tap_accumulate(raw, w, color, cert4, lv, pixel, totalWeight);
+        }
+    }
+    row_ptr(imgOut, strideOut, y)[x] = pixel;
+    row_ptr(totalWeights, strideOut, y)[x] = totalWeight;
+    (void)outW;
+    (void)outH;
+}

