@@ -231,7 +231,9 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
     }
 }
 
-template <int CFA>
+// FR = HR pixels per field texel along each axis (4: fields at LR/2, the Bayer
+// pipeline; 2: fields at LR, the monochrome pipeline; 0: any size, per-pixel fetch).
+template <int CFA, int FR>
 __global__ void __launch_bounds__(256)
     k_accumulate2xStrip(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
                         const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
@@ -246,19 +248,68 @@ __global__ void __launch_bounds__(256)
     const float posY = ((float)Y + 0.5f) / (float)hrH;
     int sx[4], sy[4];
     float kx[4], ky[4], kz[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float posX = ((float)(X0 + k) + 0.5f) / (float)hrW;
-        const float4 kp = tex4<ADDR_CLAMP>(kernelParam, posX, posY);
-        const float2 sh = tex2<ADDR_CLAMP>(shifts, posX, posY);
-        kx[k] = kp.x;
-        ky[k] = kp.y;
-        kz[k] = kp.z;
-        sx[k] = f2i(roundf(sh.x * 2.0f));
-        sy[k] = f2i(roundf(sh.y * 2.0f));
-    }
     // a strip is "safe" when no tap of its four pixels is clamped at the frame border
     bool safe = tx >= 1 && X0 + 5 <= hrW - 1 && Y >= 2 && Y + 2 <= hrH - 1;
+    if (FR == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float posX = ((float)(X0 + k) + 0.5f) / (float)hrW;
+            const float4 kp = tex4<ADDR_CLAMP>(kernelParam, posX, posY);
+            const float2 sh = tex2<ADDR_CLAMP>(shifts, posX, posY);
+            kx[k] = kp.x;
+            ky[k] = kp.y;
+            kz[k] = kp.z;
+            sx[k] = f2i(roundf(sh.x * 2.0f));
+            sy[k] = f2i(roundf(sh.y * 2.0f));
+        }
+    } else {
+        // The four pixels of a strip read the same few field texels: fetch them once
+        // (FR=4: 3 columns x 2 rows, FR=2: 4 x 2) and interpolate with exactly the
+        // arithmetic of tex_coord/lerp4, so roundf(2*flow) stays bit-identical.
+        constexpr int NC = FR == 4 ? 3 : 4;
+        const int fw = kernelParam.width, fh = kernelParam.height;  // == shifts' size (checked on the host)
+        float yB = posY * (float)fh - 0.5f;
+        if (!finitef(yB)) yB = 0.0f;
+        const float fy = floorf(yB);
+        const float b = yB - fy;
+        const int j0 = clampi(f2i(fy), 0, fh - 1), j1 = clampi(f2i(fy) + 1, 0, fh - 1);
+        const int cbase = clampi(FR == 4 ? tx - 1 : 2 * tx - 1, 0, fw - NC);
+        float K0[NC][3], K1[NC][3], F0[NC][2], F1[NC][2];
+        {
+            const float4* k0 = row_ptr((const float4*)kernelParam.ptr, kernelParam.pitch, j0) + cbase;
+            const float4* k1 = row_ptr((const float4*)kernelParam.ptr, kernelParam.pitch, j1) + cbase;
+            const float2* f0 = row_ptr((const float2*)shifts.ptr, shifts.pitch, j0) + cbase;
+            const float2* f1 = row_ptr((const float2*)shifts.ptr, shifts.pitch, j1) + cbase;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const float4 u = k0[c], v = k1[c];
+                const float2 p = f0[c], q = f1[c];
+                K0[c][0] = u.x; K0[c][1] = u.y; K0[c][2] = u.z;
+                K1[c][0] = v.x; K1[c][1] = v.y; K1[c][2] = v.z;
+                F0[c][0] = p.x; F0[c][1] = p.y;
+                F1[c][0] = q.x; F1[c][1] = q.y;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float posX = ((float)(X0 + k) + 0.5f) / (float)hrW;
+            float xB = posX * (float)fw - 0.5f;
+            if (!finitef(xB)) xB = 0.0f;
+            const float fx = floorf(xB);
+            const float a = xB - fx;
+            // texel column predicted from the strip geometry; verified against the float path
+            const int ci = FR == 4 ? (k < 2 ? 0 : 1) : (k == 0 ? 0 : (k == 3 ? 2 : 1));
+            safe = safe && (f2i(fx) == cbase + ci) && (cbase + ci + 1 <= fw - 1);
+            kx[k] = lerp4(K0[ci][0], K0[ci + 1][0], K1[ci][0], K1[ci + 1][0], a, b);
+            ky[k] = lerp4(K0[ci][1], K0[ci + 1][1], K1[ci][1], K1[ci + 1][1], a, b);
+            kz[k] = lerp4(K0[ci][2], K0[ci + 1][2], K1[ci][2], K1[ci + 1][2], a, b);
+            const float ux = lerp4(F0[ci][0], F0[ci + 1][0], F1[ci][0], F1[ci + 1][0], a, b);
+            const float uy = lerp4(F0[ci][1], F0[ci + 1][1], F1[ci][1], F1[ci + 1][1], a, b);
+            sx[k] = f2i(roundf(ux * 2.0f));
+            sy[k] = f2i(roundf(uy * 2.0f));
+        }
+        safe = safe && (f2i(fy) >= 0) && (f2i(fy) + 1 <= fh - 1);
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int qx = X0 + k + sx[k] - 2, qy = Y + sy[k] - 2;
@@ -327,8 +378,17 @@ void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pi
                   mfsr_tex2d kp, mfsr_tex2d sh, Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut,
                   int strideMask, int cfaPacked)
 {
-    hipLaunchKernelGGL((k_accumulate2xStrip<CFA>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX, dimY,
-                       strideOut, strideMask, cfaPacked);
+    const int hrW = 2 * dimX, hrH = 2 * dimY;
+    const bool same = kp.width == sh.width && kp.height == sh.height;
+    if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4)
+        hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 4>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
+                           dimY, strideOut, strideMask, cfaPacked);
+    else if (same && kp.width * 2 == hrW && kp.height * 2 == hrH && kp.width >= 4)
+        hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 2>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
+                           dimY, strideOut, strideMask, cfaPacked);
+    else
+        hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 0>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
+                           dimY, strideOut, strideMask, cfaPacked);
 }
 
 }  // namespace

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/golden_v1.npz from the CPU oracle.
+
+The reference ships no expected outputs for this path, so these
+fixtures are NOT reference outputs: they are seeded inputs plus the outputs of this
+repository's oracle (oracle/*.c, a restatement of the reference kernels), frozen so that
+(a) the oracle cannot drift silently between rounds and (b) the GPU path can be checked on
+a box without rebuilding anything.  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from tests.kernels import F2, F3, OracleKernels, Tex, pitch_of  # noqa: E402
+
+
+def build():
+    orc = OracleKernels()
+    r = np.random.default_rng(20260104)
+    g = {}
+    orc.set_cfa([0, 1, 1, 2])
+    # A1
+    raw = r.integers(0, 4096, (32, 48), dtype=np.uint16)
+    half = np.zeros((16, 24, 3), np.float32)
+    orc.call("deBayersSubSample3", raw, half, 4095.0, 24, 16, pitch_of(half))
+    g["raw"], g["deBayersSubSample3"] = raw, half
+    # A2+A3
+    rawf = raw.astype(np.float32)
+    rgb = np.zeros((32, 48, 3), np.float32)
+    bp, sc = F3([256, 256, 256]), F3(np.float32(1) / np.float32([3839, 3839, 3839]))
+    orc.call("deBayerGreenKernel", 48, 32, rawf, pitch_of(rawf), rgb, pitch_of(rgb), bp, sc)
+    orc.call("deBayerRedBlueKernel", 48, 32, rawf, pitch_of(rawf), rgb, pitch_of(rgb), bp, sc)
+    g["deBayer"] = rgb
+    # G2 (reference geometry) and full-frame x2
+    kp = np.zeros((16, 24, 4), np.float32)
+    kp[..., 0] = r.uniform(0.1, 2, (16, 24))
+    kp[..., 1] = r.uniform(0.1, 2, (16, 24))
+    kp[..., 2] = r.uniform(-0.1, 0.1, (16, 24))
+    flow = r.uniform(-3, 3, (16, 24, 2)).astype(np.float32)
+    mask = r.random((16, 24, 4), dtype=np.float32)
+    g["kp"], g["flow"], g["mask"] = kp, flow, mask
+    white, black = F3([3839, 3839, 3839]), F3([256, 256, 256])
+    acc = np.zeros((32, 48, 3), np.float32)
+    tw = np.zeros_like(acc)
+    orc.call("accumulateImagesSuperRes", raw, acc, tw, mask, Tex(kp), Tex(flow), white, black, 48, 32, pitch_of(acc),
+             pitch_of(mask))
+    g["accumulateImagesSuperRes_img"], g["accumulateImagesSuperRes_w"] = acc, tw
+    acc2 = np.zeros((64, 96, 3), np.float32)
+    tw2 = np.zeros_like(acc2)
+    orc.call("accumulateSuperResFull", raw, acc2, tw2, mask, Tex(kp), Tex(flow), white, black, 48, 32, 2, pitch_of(acc2),
+             pitch_of(mask))
+    g["accumulateSuperResFull_img"], g["accumulateSuperResFull_w"] = acc2, tw2
+    # F1
+    ref3 = r.random((16, 24, 3), dtype=np.float32)
+    mov3 = np.clip(ref3 + r.normal(0, 0.03, ref3.shape), 0, 1).astype(np.float32)
+    rm = np.zeros((16, 24, 4), np.float32)
+    orc.call("ComputeRobustnessMask", ref3, mov3, rm, Tex(flow), 24, 16, pitch_of(ref3), pitch_of(rm), 1e-4, 1e-6, 0.8)
+    g["rob_ref"], g["rob_mov"], g["ComputeRobustnessMask"] = ref3, mov3, rm
+    # D: one LK iteration chain
+    y, x = np.mgrid[0:40, 0:56].astype(np.float32)
+    img_a = (0.5 + 0.2 * np.sin(0.3 * x + 0.1 * y) + 0.2 * np.cos(0.22 * y)).astype(np.float32)
+    img_b = (0.5 + 0.2 * np.sin(0.3 * (x - 0.4) + 0.1 * (y + 0.3)) + 0.2 * np.cos(0.22 * (y + 0.3))).astype(np.float32)
+    fl = np.zeros((40, 56, 2), np.float32)
+    warped = np.zeros((40, 56), np.float32)
+    Ix, Iy, Iz = (np.zeros((40, 56), np.float32) for _ in range(3))
+    orc.call("WarpingKernel", 56, 40, pitch_of(warped), Tex(fl), warped, Tex(img_b))
+    orc.call("ComputeDerivativesKernel", 56, 40, pitch_of(Ix), Ix, Iy, Iz, Tex(warped), Tex(img_a))
+    orc.call("lucasKanadeOptim", fl, Ix, Iy, Iz, pitch_of(fl), pitch_of(Ix), 56, 40, 3, 1e-4)
+    g["lk_ref"], g["lk_mov"], g["lk_flow_after_1_iteration"] = img_a, img_b, fl
+    # B: tile chain on one level
+    T, S, tcx, tcy = 16, 3, 3, 2
+    n, L, R = tcx * tcy, T + 2 * S, 2 * S + 1
+    base = r.random((48, 64), dtype=np.float32)
+    tref = np.ascontiguousarray(base[4:36, 4:52])
+    tmov = np.ascontiguousarray(base[5:37, 3:51])
+    pre = np.zeros((tcy, tcx, 2), np.float32)
+    rt, mt, cc, bx, by = (np.zeros((n, L, L), np.float32) for _ in range(5))
+    sq = np.zeros(n, np.float32)
+    dist = np.zeros((n, R, R), np.float32)
+    coord = np.zeros((tcy, tcx, 2), np.float32)
+    z = F2([0, 0])
+    orc.call("convertToTilesOverlapBorder", tref, rt, 48, 32, pitch_of(tref), S, T, tcx, tcy, z, 0.0)
+    orc.call("convertToTilesOverlapPreShift", tmov, mt, pre, pitch_of(pre), 48, 32, pitch_of(tmov), S, T, tcx, tcy, z, 0.0)
+    orc.call("crossCorrelateTiles", rt, mt, cc, S, T, n)
+    orc.call("squaredSum", rt, sq, S, T, n)
+    orc.call("boxFilterWithBorderX", mt, bx, S, T, n)
+    orc.call("boxFilterWithBorderY", bx, by, S, T, n)
+    orc.call("normalizedCC", cc, sq, by, dist, S, T, n)
+    orc.call("findMinimum", dist, coord, pitch_of(coord), S, n, tcx, 0.0)
+    g["tile_ref"], g["tile_mov"], g["tile_dist"], g["tile_coord"] = tref, tmov, dist, coord
+    # E3
+    ten = (r.random((8, 12, 3), dtype=np.float32) * np.float32(1e-3)).astype(np.float32)
+    ten[..., 2] *= 0.3
+    kpar = ten.copy()
+    orc.call("ComputeKernelParam", kpar, 12, 8, pitch_of(kpar), 0.005, 0.05, 0.3, 2.0, 2.0, 2.0)
+    g["tensor"], g["ComputeKernelParam"] = ten, kpar
+    return g
+
+
+if __name__ == "__main__":
+    g = build()
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_v1.npz")
+    np.savez_compressed(out, **g)
+    print("wrote", out, os.path.getsize(out), "bytes,", len(g), "arrays")

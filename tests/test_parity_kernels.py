@@ -164,8 +164,9 @@ def test_accumulateSuperResFull(orc, hip, scale):
     np.testing.assert_allclose(hw_, ow, rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("field", ["quarter", "half", "odd"])
 @pytest.mark.parametrize("pat", ["RGGB", "BGGR", "GRBG", "GBRG", "MONO"])
-def test_accumulate_x2_strip_kernel(orc, hip, pat):
+def test_accumulate_x2_strip_kernel(orc, hip, pat, field):
     """The restructured x2 strip kernel (accumulate_fast.hip) against the oracle AND against the
     straight kernel: big flows so that border strips take the per-pixel fallback, NaN certainties,
     hostile kernel parameters, every supported CFA."""
@@ -175,10 +176,14 @@ def test_accumulate_x2_strip_kernel(orc, hip, pat):
     hip.set_cfa(cfa)
     white, black = F3([3839, 3700, 3900]), F3([256, 260, 250])
 
+    # field resolution: HR/4 (Bayer pipeline, shared-texel path FR=4), HR/2 (mono pipeline, FR=2),
+    # anything else (per-pixel fetch, FR=0)
+    fh, fw = {"quarter": (H // 2, W // 2), "half": (H, W), "odd": (H // 2 + 3, W // 2 + 5)}[field]
+
     def make():
         raw, imgOut, tw, mask = _accum_inputs(90, W, H, W * s, H * s, nan_frac=0.01)
-        kp = _kernel_field(91, H // 2, W // 2, 4)
-        sh = rng(92).uniform(-6, 6, (H // 2, W // 2, 2)).astype(np.float32)
+        kp = _kernel_field(91, fh, fw, 4)
+        sh = rng(92).uniform(-6, 6, (fh, fw, 2)).astype(np.float32)
         sh[10:14, 10:14] = 1e9       # wild flow -> fallback path
         sh[20, 20] = np.nan
         args = (raw, imgOut, tw, mask, Tex(kp), Tex(sh), white, black, W, H, s, pitch_of(imgOut), pitch_of(mask))
