@@ -144,6 +144,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:  # bring the RCCL communicator up outside the timed region even with --warmup 0
+        dist.all_reduce(torch.zeros(1, device=dev))
     for _ in range(args.warmup):
         step()
     barrier()
