@@ -19,7 +19,8 @@ from typing import Dict, List, Tuple
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG_DIR)
 HEADER_PATH = os.path.join(_ROOT, "include", "mfsr.h")
-LIB_PATH = os.path.join(_PKG_DIR, "lib", "libmfsr_hip.so")
+# MFSR_LIB overrides the library path (A/B builds of the same C-ABI during kernel tuning)
+LIB_PATH = os.environ.get("MFSR_LIB") or os.path.join(_PKG_DIR, "lib", "libmfsr_hip.so")
 
 
 class Float2(ctypes.Structure):

@@ -29,6 +29,8 @@
 // normalisation), so results agree with it to ~1e-6 relative (tests: 2e-5), not
 // bit for bit.  Pixels whose taps would be clamped at the frame border (or whose
 // flow is wild) take the straight per-pixel path inside the same launch.
+#include <cstdlib>
+
 #include "accumulate_common.hpp"
 
 namespace {
@@ -64,12 +66,20 @@ struct StripLevels {
 
 __device__ __forceinline__ float sane(float c) { return finitef(c) ? c : 0.0f; }
 
+// fast-path admission: kernel parameters form a positive semi-definite inverse covariance
+// (so every tap exponent is >= 0 and every weight is in [0,1]); NaN fails the comparisons
+__device__ __forceinline__ bool psd_ok(float kx, float ky, float kz)
+{
+    return kx >= 0.0f && ky >= 0.0f && kz * kz <= kx * ky && kx < 1e30f && ky < 1e30f;
+}
+
 // one HR pixel of a safe strip.  K = position in the strip (compile time).
-template <int K, int CFA>
+// MaskF: float mval(int jt, int cell, int ch) -> sanitised certainty of channel ch in mask cell
+// `cell` (0..2, relative to the strip) on the mask row that tap row jt reads.
+template <int K, int CFA, typename MaskF>
 __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float kx, float ky, float kz,
-                                            const uint16_t* __restrict__ raw, int dimX, const float (&M0)[3][3],
-                                            const float (&M1)[3][3], int sw, const StripLevels& lv, float* accP,
-                                            float* accW)
+                                            const uint16_t* __restrict__ raw, int dimX, MaskF mval,
+                                            const StripLevels& lv, float* accP, float* accW)
 {
     const int qx = X + sx - 2, qy = Y + sy - 2;
     const int x0 = qx >> 1, y0 = qy >> 1;
@@ -98,9 +108,9 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
             // (px*px*kx + 2*px*py*kz) + py*py*ky with the reference's two rounded adds (:427)
             float e = (Ax[apx] + (float)(2 * px * py) * kz) + Cy[apy];
             float t = e * -0.72134752044448170368f;  // exp(-e/2) = exp2(e * -0.5*log2(e))
-            float v = __builtin_amdgcn_exp2f(t);
-            if (!finitef(v)) v = (px * py == 0) ? 1.0f : 0.0f;  // :429-430
-            w[n] = v;
+            // the caller admits only positive semi-definite kernel parameters to this path, so
+            // e >= 0 and w = exp2(t) is in [0, 1]: the non-finite rule of :429-430 cannot fire
+            w[n] = __builtin_amdgcn_exp2f(t);
         }
     }
 
@@ -141,11 +151,7 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
             const int cell = c == 0 ? cellLo : cellHi;
             float m[3];
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                if (jt == 0) m[ch] = M0[cell][ch];
-                else if (jt == 4) m[ch] = M1[cell][ch];
-                else m[ch] = (jt >= sw) ? M1[cell][ch] : M0[cell][ch];
-            }
+            for (int ch = 0; ch < 3; ch++) m[ch] = mval(jt, cell, ch);
             cA[c] = ya ? m[Cfa<CFA>::col(1, 0)] : m[Cfa<CFA>::col(0, 0)];
             cB[c] = ya ? m[Cfa<CFA>::col(1, 1)] : m[Cfa<CFA>::col(0, 1)];
         }
@@ -214,15 +220,18 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
     if (nG == 4) {  // monochrome
         chS[1] = (S[0][0] + S[0][1]) + (S[1][0] + S[1][1]);
         chW[1] = (W[0][0] + W[0][1]) + (W[1][0] + W[1][1]);
-    } else {  // Bayer: one red, one blue, two greens (summed directly: no cancellation)
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            constexpr int dummy2 = 0;
-            (void)dummy2;
-            const int c = Cfa<CFA>::col(a >> 1, a & 1);
-            chS[c] += at_pos(S, a >> 1, a & 1);
-            chW[c] += at_pos(W, a >> 1, a & 1);
-        }
+    } else {  // Bayer: one red, one blue, two greens
+        // weights are in [0,1] on this path (PSD kernel parameters), so the two green positions
+        // can be taken as total - red - blue without cancellation trouble
+        constexpr int pr = Cfa<CFA>::pos_of(MFSR_RED), pb = Cfa<CFA>::pos_of(MFSR_BLUE);
+        const float totS = (S[0][0] + S[0][1]) + (S[1][0] + S[1][1]);
+        const float totW = (W[0][0] + W[0][1]) + (W[1][0] + W[1][1]);
+        chS[0] = at_pos(S, pr >> 1, pr & 1);
+        chW[0] = at_pos(W, pr >> 1, pr & 1);
+        chS[2] = at_pos(S, pb >> 1, pb & 1);
+        chW[2] = at_pos(W, pb >> 1, pb & 1);
+        chS[1] = (totS - chS[0]) - chS[2];
+        chW[1] = (totW - chW[0]) - chW[2];
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -311,6 +320,8 @@ __global__ void __launch_bounds__(256)
         safe = safe && (f2i(fy) >= 0) && (f2i(fy) + 1 <= fh - 1);
     }
 #pragma unroll
+    for (int k = 0; k < 4; k++) safe = safe && psd_ok(kx[k], ky[k], kz[k]);
+#pragma unroll
     for (int k = 0; k < 4; k++) {
         const int qx = X0 + k + sx[k] - 2, qy = Y + sy[k] - 2;
         safe = safe && qx >= 0 && ((qx + 4) >> 1) <= dimX - 1 && qy >= 0 && ((qy + 4) >> 1) <= dimY - 1;
@@ -358,10 +369,142 @@ __global__ void __launch_bounds__(256)
         }
     }
 
-    strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kx[0], ky[0], kz[0], raw, dimX, M0, M1, sw, lv, accP, accW);
-    strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kx[1], ky[1], kz[1], raw, dimX, M0, M1, sw, lv, accP, accW);
-    strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kx[2], ky[2], kz[2], raw, dimX, M0, M1, sw, lv, accP, accW);
-    strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kx[3], ky[3], kz[3], raw, dimX, M0, M1, sw, lv, accP, accW);
+    auto mval = [&](int jt, int cell, int ch) {
+        // mask row (Y-2+jt)>>2 is r0 for jt < sw and r0+1 otherwise (wave-uniform)
+        return jt == 0 ? M0[cell][ch] : (jt == 4 ? M1[cell][ch] : ((jt >= sw) ? M1[cell][ch] : M0[cell][ch]));
+    };
+    strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kx[0], ky[0], kz[0], raw, dimX, mval, lv, accP, accW);
+    strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kx[1], ky[1], kz[1], raw, dimX, mval, lv, accP, accW);
+    strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kx[2], ky[2], kz[2], raw, dimX, mval, lv, accP, accW);
+    strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kx[3], ky[3], kz[3], raw, dimX, mval, lv, accP, accW);
+
+    pP[0] = make_float4(accP[0], accP[1], accP[2], accP[3]);
+    pP[1] = make_float4(accP[4], accP[5], accP[6], accP[7]);
+    pP[2] = make_float4(accP[8], accP[9], accP[10], accP[11]);
+    pW[0] = make_float4(accW[0], accW[1], accW[2], accW[3]);
+    pW[1] = make_float4(accW[4], accW[5], accW[6], accW[7]);
+    pW[2] = make_float4(accW[8], accW[9], accW[10], accW[11]);
+}
+
+// ---- LDS-tiled variant (fields at HR/4: the Bayer pipeline) ------------------------------
+// One 64x4 workgroup covers a 256 x 4 HR tile.  The kernel-parameter / flow texels and the
+// certainty texels that the tile touches (3 rows x 66 columns each) are staged once in LDS
+// (certainties sanitised while staging), so a thread keeps neither field texels nor
+// certainty texels in registers across its four pixels: fewer global loads (6.2 KB per
+// workgroup instead of ~46 KB) and a smaller register footprint (more waves per SIMD).
+#define TILE_COLS 66
+#ifndef TILE_WAVES
+#define TILE_WAVES 4
+#endif
+template <int CFA>
+__global__ void __launch_bounds__(256, TILE_WAVES)
+    k_accumulate2xTile(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
+                       const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
+                       StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
+{
+    __shared__ float4 sK[3][TILE_COLS];
+    __shared__ float2 sF[3][TILE_COLS];
+    __shared__ float4 sM[3][TILE_COLS];
+    const int lx = threadIdx.x, ly = threadIdx.y;
+    const int tx = blockIdx.x * 64 + lx;
+    const int Y = blockIdx.y * 4 + ly;
+    const int hrW = 2 * dimX, hrH = 2 * dimY;
+    const int X0 = 4 * tx;
+    const int fw = kernelParam.width, fh = kernelParam.height;  // == hrW/4, hrH/4 (checked on the host)
+    const int mw = dimX / 2, mh = dimY / 2;                       // certainty mask size
+    {
+        const int t = ly * 64 + lx;
+        if (t < 3 * TILE_COLS) {
+            const int r = t / TILE_COLS, c = t - r * TILE_COLS;
+            const int gy = (int)blockIdx.y - 1 + r, gx = (int)blockIdx.x * 64 - 1 + c;
+            const int fy = clampi(gy, 0, fh - 1), fx = clampi(gx, 0, fw - 1);
+            sK[r][c] = row_ptr((const float4*)kernelParam.ptr, kernelParam.pitch, fy)[fx];
+            sF[r][c] = row_ptr((const float2*)shifts.ptr, shifts.pitch, fy)[fx];
+            const float4 m = row_ptr(certaintyMask, strideMask, clampi(gy, 0, mh - 1))[clampi(gx, 0, mw - 1)];
+            sM[r][c] = make_float4(sane(m.x), sane(m.y), sane(m.z), 0.0f);
+        }
+    }
+    __syncthreads();
+    if (X0 >= hrW || Y < 1 || Y >= hrH - 1) return;
+
+    // field row: the same float path as tex_coord; LDS row predicted from ly and verified
+    const float posY = ((float)Y + 0.5f) / (float)hrH;
+    float yB = posY * (float)fh - 0.5f;
+    if (!finitef(yB)) yB = 0.0f;
+    const float fyf = floorf(yB);
+    const float b = yB - fyf;
+    const int fr = ly < 2 ? 0 : 1;  // LDS row of texel row j0 = floor(yB)
+    bool safe = tx >= 1 && X0 + 5 <= hrW - 1 && Y >= 2 && Y + 2 <= hrH - 1;
+    safe = safe && (f2i(fyf) == (int)blockIdx.y - 1 + fr) && f2i(fyf) >= 0 && f2i(fyf) + 1 <= fh - 1;
+
+    int sx[4], sy[4];
+    float av[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float posX = ((float)(X0 + k) + 0.5f) / (float)hrW;
+        float xB = posX * (float)fw - 0.5f;
+        if (!finitef(xB)) xB = 0.0f;
+        const float fxf = floorf(xB);
+        av[k] = xB - fxf;
+        const int ci = k < 2 ? 0 : 1;
+        safe = safe && (f2i(fxf) == tx - 1 + ci) && (tx + ci <= fw - 1);
+        const float2 t00 = sF[fr][lx + ci], t10 = sF[fr][lx + ci + 1], t01 = sF[fr + 1][lx + ci], t11 = sF[fr + 1][lx + ci + 1];
+        const float ux = lerp4(t00.x, t10.x, t01.x, t11.x, av[k], b);
+        const float uy = lerp4(t00.y, t10.y, t01.y, t11.y, av[k], b);
+        sx[k] = f2i(roundf(ux * 2.0f));
+        sy[k] = f2i(roundf(uy * 2.0f));
+        const int qx = X0 + k + sx[k] - 2, qy = Y + sy[k] - 2;
+        safe = safe && qx >= 0 && ((qx + 4) >> 1) <= dimX - 1 && qy >= 0 && ((qy + 4) >> 1) <= dimY - 1;
+        safe = safe && sx[k] > -(1 << 20) && sx[k] < (1 << 20) && sy[k] > -(1 << 20) && sy[k] < (1 << 20);
+    }
+    auto kfetch = [&](int k, float& kx, float& ky, float& kz) {
+        const int ci = k < 2 ? 0 : 1;
+        const float4 t00 = sK[fr][lx + ci], t10 = sK[fr][lx + ci + 1], t01 = sK[fr + 1][lx + ci], t11 = sK[fr + 1][lx + ci + 1];
+        kx = lerp4(t00.x, t10.x, t01.x, t11.x, av[k], b);
+        ky = lerp4(t00.y, t10.y, t01.y, t11.y, av[k], b);
+        kz = lerp4(t00.z, t10.z, t01.z, t11.z, av[k], b);
+    };
+    float kxa[4], kya[4], kza[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        kfetch(k, kxa[k], kya[k], kza[k]);
+        safe = safe && psd_ok(kxa[k], kya[k], kza[k]);
+    }
+    if (!safe) {
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            const int X = X0 + k;
+            if (X >= 1 && X < hrW - 1)
+                accumulate_pixel_generic<GEOM_FULL, true>(X, Y, raw, imgOut, totalWeights, certaintyMask, kernelParam,
+                                                          shifts, glv, dimX, dimY, 2, strideOut, strideMask, cfaPacked);
+        }
+        return;
+    }
+
+    float4* pP = (float4*)((char*)imgOut + (size_t)Y * strideOut + (size_t)X0 * 12);
+    float4* pW = (float4*)((char*)totalWeights + (size_t)Y * strideOut + (size_t)X0 * 12);
+    float accP[12], accW[12];
+    {
+        const float4 a0 = pP[0], a1 = pP[1], a2 = pP[2];
+        const float4 b0 = pW[0], b1 = pW[1], b2 = pW[2];
+        accP[0] = a0.x; accP[1] = a0.y; accP[2] = a0.z; accP[3] = a0.w;
+        accP[4] = a1.x; accP[5] = a1.y; accP[6] = a1.z; accP[7] = a1.w;
+        accP[8] = a2.x; accP[9] = a2.y; accP[10] = a2.z; accP[11] = a2.w;
+        accW[0] = b0.x; accW[1] = b0.y; accW[2] = b0.z; accW[3] = b0.w;
+        accW[4] = b1.x; accW[5] = b1.y; accW[6] = b1.z; accW[7] = b1.w;
+        accW[8] = b2.x; accW[9] = b2.y; accW[10] = b2.z; accW[11] = b2.w;
+    }
+
+    // certainty: LDS row of the mask row that tap row jt reads = ((ly + jt - 2) >> 2) + 1; column lx + cell
+    auto mval = [&](int jt, int cell, int ch) {
+        const int mr = ((ly + jt - 2) >> 2) + 1;
+        const float* p = (const float*)&sM[mr][lx + cell];
+        return p[ch];
+    };
+    strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
+    strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
+    strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
+    strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
 
     pP[0] = make_float4(accP[0], accP[1], accP[2], accP[3]);
     pP[1] = make_float4(accP[4], accP[5], accP[6], accP[7]);
@@ -373,6 +516,8 @@ __global__ void __launch_bounds__(256)
 
 constexpr int pack_cfa(int c00, int c01, int c10, int c11) { return c00 | (c01 << 2) | (c10 << 4) | (c11 << 6); }
 
+bool g_strip_use_tile = true;  // MFSR_STRIP_TILE=0 in the environment selects the register-only strip kernel
+
 template <int CFA>
 void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pix3* imgOut, pix3* tw, const float4* mask,
                   mfsr_tex2d kp, mfsr_tex2d sh, Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut,
@@ -380,7 +525,11 @@ void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pi
 {
     const int hrW = 2 * dimX, hrH = 2 * dimY;
     const bool same = kp.width == sh.width && kp.height == sh.height;
-    if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4)
+    if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4 && (dimX % 4) == 0 && (dimY % 4) == 0 &&
+        g_strip_use_tile)
+        hipLaunchKernelGGL((k_accumulate2xTile<CFA>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX, dimY,
+                           strideOut, strideMask, cfaPacked);
+    else if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4)
         hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 4>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
                            dimY, strideOut, strideMask, cfaPacked);
     else if (same && kp.width * 2 == hrW && kp.height * 2 == hrH && kp.width >= 4)
@@ -400,6 +549,12 @@ int mfsr_try_launch_accumulate2x_strip(const uint16_t* dataIn, mfsr_float3* imgO
                                        mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int strideOut,
                                        int strideMask, mfsr_stream_t stream)
 {
+    static const bool env_read = [] {
+        const char* e = getenv("MFSR_STRIP_TILE");
+        if (e && e[0] == '0') g_strip_use_tile = false;
+        return true;
+    }();
+    (void)env_read;
     int cfa[4];
     mfsr_get_cfa_pattern(cfa);
     for (int i = 0; i < 4; i++)
