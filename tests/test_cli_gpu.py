@@ -1,0 +1,51 @@
+"""The reference-style CLI (apps/multi_frame_sr.cpp, drop-in for
+finalProject/Project/multi_frame_sr.cpp:122-210): same argv, same prints, same output files."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "apps", "multi_frame_sr")
+
+
+def test_cli_usage_matches_reference():
+    if not os.path.exists(CLI):
+        pytest.skip("apps/multi_frame_sr not built")
+    p = subprocess.run([CLI, "only", "two"], capture_output=True, text=True)
+    assert p.returncode != 0
+    assert "./multi_frame_sr optFlowName inputName iterations" in p.stdout       # multi_frame_sr.cpp:138
+    p = subprocess.run([CLI, "farneback", "nowhere", "3"], capture_output=True, text=True)
+    assert "wrong input" in p.stdout                                             # :161
+    p = subprocess.run([CLI, "simple", "city", "3"], capture_output=True, text=True)
+    assert "Incorrect Optical Flow algorithm - simple" in p.stderr               # :84
+
+
+@pytest.mark.gpu
+def test_cli_city_burst(tmp_path):
+    from PIL import Image
+    import torch
+    from multi_frame_super_resolution_amd.synth import _scene, _shifted
+    assert os.path.exists(CLI), "build apps/multi_frame_sr first (__graft_entry__.build())"
+    # 5 frames 512x256 RGB8 like the bundled test_opencv/img_00000[0-4].png, pure translations
+    gen = torch.Generator().manual_seed(3)
+    scene = _scene(256 * 2 + 64, 512 * 2 + 64, gen, "cpu")
+    shifts = [(0, 0), (1.3, -2.1), (-3.2, 0.6), (2.4, 2.9), (-1.1, -1.7)]
+    for i, (dx, dy) in enumerate(shifts):
+        sh = _shifted(scene, dx * 2, dy * 2)[:, 32:32 + 512, 32:32 + 1024]
+        lr = torch.nn.functional.avg_pool2d(sh[None], 2)[0]
+        img = (lr.permute(1, 2, 0).clamp(0, 1) * 255).round().byte().numpy()
+        Image.fromarray(img).save(tmp_path / f"img_{i + 1:06d}.png")          # reference indexes 1..5 (:171)
+    p = subprocess.run([CLI, "farneback", "city", "3"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert " sec" in p.stdout and " FPS" in p.stdout                             # :205-206
+    out = np.asarray(Image.open(tmp_path / "city_farneback_sr_result.png"))      # :207
+    out2 = np.asarray(Image.open(tmp_path / "city_farneback_sr2_result.png"))    # :209
+    assert out.shape == (512, 1024, 3) and out2.shape == out.shape
+    gt = (scene[:, 32:32 + 512, 32:32 + 1024].permute(1, 2, 0).clamp(0, 1) * 255).numpy()
+    mse = np.mean((out[32:-32, 32:-32].astype(np.float64) - gt[32:-32, 32:-32]) ** 2)
+    psnr = 10 * np.log10(255.0 ** 2 / mse)
+    print("CLI x2 result PSNR vs scene:", psnr)
+    assert psnr > 24.0
+    assert (out2[0] == 0).all() and (out2[:, 0] == 0).all()                      # sharpenImg2 zeroes the ring (:114-117)
