@@ -200,7 +200,7 @@ def main():
                 "kernels": "unfused (one launch per reference kernel)" if args.unfused else "fused",
             },
             "roofline": {
-                "kernel": "k_accumulateSuperRes<GEOM_FULL,fast> (warp+fuse, one launch per frame)",
+                "kernel": ("k_accumulate2xTile / k_accumulate2xStrip" if s == 2 else "k_accumulateSuperRes<GEOM_FULL,fast>") + " (warp+fuse, accumulateSuperResFull, one launch per frame)",
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS,

@@ -75,18 +75,16 @@ __device__ __forceinline__ int floordiv_pos(int a, int s)
 // One output pixel of accumulateImagesSuperRes (:379-468) / its full-frame
 // generalisation, straight from the reference: read-modify-write of imgOut and
 // totalWeights at (x, y).  Caller guarantees 1 <= x < outW-1, 1 <= y < outH-1.
+// core: accumulates the 25 taps of output pixel (x, y) into the register values pixel / totalWeight
 template <int GEOM, bool FAST>
-__device__ __forceinline__ void accumulate_pixel_generic(int x, int y, const uint16_t* __restrict__ dataIn,
-                                                         pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
-                                                         const float4* __restrict__ certaintyMask,
-                                                         const mfsr_tex2d& kernelParam, const mfsr_tex2d& shifts,
-                                                         const Levels3& lv, int dimX, int dimY, int scale, int strideOut,
-                                                         int strideMask, int cfa)
+__device__ __forceinline__ void accumulate_pixel_core(int x, int y, const uint16_t* __restrict__ dataIn,
+                                                      const float4* __restrict__ certaintyMask,
+                                                      const mfsr_tex2d& kernelParam, const mfsr_tex2d& shifts,
+                                                      const Levels3& lv, int dimX, int dimY, int scale, int strideMask,
+                                                      int cfa, pix3& pixel, pix3& totalWeight)
 {
     const int outW = (GEOM == GEOM_CROP) ? dimX : dimX * scale;
     const int outH = (GEOM == GEOM_CROP) ? dimY : dimY * scale;
-    pix3 pixel = row_ptr(imgOut, strideOut, y)[x];
-    pix3 totalWeight = row_ptr(totalWeights, strideOut, y)[x];
 
     float posX, posY, fscale;
     if (GEOM == GEOM_CROP) {
@@ -136,8 +134,22 @@ __device__ __forceinline__ void accumulate_pixel_generic(int x, int y, const uin
             tap_accumulate(raw, w, color, cert4, lv, pixel, totalWeight);
         }
     }
-    row_ptr(imgOut, strideOut, y)[x] = pixel;
-    row_ptr(totalWeights, strideOut, y)[x] = totalWeight;
     (void)outW;
     (void)outH;
+}
+
+template <int GEOM, bool FAST>
+__device__ __forceinline__ void accumulate_pixel_generic(int x, int y, const uint16_t* __restrict__ dataIn,
+                                                         pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
+                                                         const float4* __restrict__ certaintyMask,
+                                                         const mfsr_tex2d& kernelParam, const mfsr_tex2d& shifts,
+                                                         const Levels3& lv, int dimX, int dimY, int scale, int strideOut,
+                                                         int strideMask, int cfa)
+{
+    pix3 pixel = row_ptr(imgOut, strideOut, y)[x];
+    pix3 totalWeight = row_ptr(totalWeights, strideOut, y)[x];
+    accumulate_pixel_core<GEOM, FAST>(x, y, dataIn, certaintyMask, kernelParam, shifts, lv, dimX, dimY, scale, strideMask,
+                                      cfa, pixel, totalWeight);
+    row_ptr(imgOut, strideOut, y)[x] = pixel;
+    row_ptr(totalWeights, strideOut, y)[x] = totalWeight;
 }

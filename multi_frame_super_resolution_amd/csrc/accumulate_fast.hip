@@ -76,6 +76,16 @@ __device__ __forceinline__ bool psd_ok(float kx, float ky, float kz)
 // one HR pixel of a safe strip.  K = position in the strip (compile time).
 // MaskF: float mval(int jt, int cell, int ch) -> sanitised certainty of channel ch in mask cell
 // `cell` (0..2, relative to the strip) on the mask row that tap row jt reads.
+// Per-lane two-way selects are written as bit-field inserts on lane masks (v_bitop3_b32, a plain
+// 3-operand VALU op) instead of v_cndmask_b32 + v_cmp: on gfx950 v_cndmask/v_cmp issue at ~0.69x the
+// rate of v_add/v_fma/v_bitop3 (tools/ubench/valu_ops.hip: 1.95 vs 1.3 ns per wave-instruction per
+// SIMD) and selects are a third of this kernel's instructions.
+__device__ __forceinline__ float selm(uint32_t m, float a, float b)  // m == ~0u ? a : b
+{
+    // one v_bitop3_b32 with truth table 0xCA = (m & a) | (~m & b)
+    return __uint_as_float(__builtin_amdgcn_bitop3_b32(m, __float_as_uint(a), __float_as_uint(b), 0xCA));
+}
+
 template <int K, int CFA, typename MaskF>
 __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float kx, float ky, float kz,
                                             const uint16_t* __restrict__ raw, int dimX, MaskF mval,
@@ -83,8 +93,9 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
 {
     const int qx = X + sx - 2, qy = Y + sy - 2;
     const int x0 = qx >> 1, y0 = qy >> 1;
-    const bool bx = qx & 1, by = qy & 1;
-    const bool P = x0 & 1, Q = y0 & 1;
+    // lane masks (all ones / zero) of the four parity bits
+    const uint32_t mbx = 0u - (uint32_t)(qx & 1), mby = 0u - (uint32_t)(qy & 1);
+    const uint32_t mP = 0u - (uint32_t)(x0 & 1), mQ = 0u - (uint32_t)(y0 & 1);
 
     // 3x3 raw sites
     float s[3][3];
@@ -118,8 +129,9 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
     float S[2][2] = {{0, 0}, {0, 0}}, W[2][2] = {{0, 0}, {0, 0}};
     float r1S[2], r1W[2], r3S[2], r3W[2];
 
-    const bool pA = P;         // x parity of tap columns 0, 4 (and !pA for column 2)
-    const bool pB = P != bx;   // x parity of tap column 1 (and !pB for column 3)
+    const uint32_t mA = mP;        // x parity of tap columns 0, 4 (complement for column 2)
+    const uint32_t mB = mP ^ mbx;  // x parity of tap column 1 (complement for column 3)
+    const uint32_t mY13 = mQ ^ mby;  // y parity of tap row 1 (complement for row 3)
 
 #pragma unroll
     for (int jt = 0; jt < 5; jt++) {
@@ -128,22 +140,21 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             if (jt == 0) rr[i] = s[0][i];
-            if (jt == 1) rr[i] = by ? s[1][i] : s[0][i];
+            if (jt == 1) rr[i] = selm(mby, s[1][i], s[0][i]);
             if (jt == 2) rr[i] = s[1][i];
-            if (jt == 3) rr[i] = by ? s[2][i] : s[1][i];
+            if (jt == 3) rr[i] = selm(mby, s[2][i], s[1][i]);
             if (jt == 4) rr[i] = s[2][i];
         }
-        const float v[5] = {rr[0], bx ? rr[1] : rr[0], rr[1], bx ? rr[2] : rr[1], rr[2]};
+        const float v[5] = {rr[0], selm(mbx, rr[1], rr[0]), rr[1], selm(mbx, rr[2], rr[1]), rr[2]};
 
-        // absolute y parity of the sites of this tap row
-        bool ya;
-        if (jt == 0 || jt == 4) ya = Q;
-        if (jt == 2) ya = !Q;
-        if (jt == 1) ya = Q != by;
-        if (jt == 3) ya = !(Q != by);
+        // absolute y parity of the sites of this tap row (as a lane mask)
+        uint32_t mya;
+        if (jt == 0 || jt == 4) mya = mQ;
+        if (jt == 2) mya = ~mQ;
+        if (jt == 1) mya = mY13;
+        if (jt == 3) mya = ~mY13;
 
-        // certainty texels of this tap row: mask row (Y-2+jt)>>2 is M0 for jt < sw, M1 otherwise (uniform)
-        // cells used by pixel K: (K + it + 2) >> 2
+        // certainty texels of this tap row; cells used by pixel K: (K + it + 2) >> 2
         constexpr int cellLo = (K + 0 + 2) >> 2, cellHi = (K + 4 + 2) >> 2;
         float cA[2], cB[2];  // certainty for x parity 0 / 1 in the two cells
 #pragma unroll
@@ -152,8 +163,8 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
             float m[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) m[ch] = mval(jt, cell, ch);
-            cA[c] = ya ? m[Cfa<CFA>::col(1, 0)] : m[Cfa<CFA>::col(0, 0)];
-            cB[c] = ya ? m[Cfa<CFA>::col(1, 1)] : m[Cfa<CFA>::col(0, 1)];
+            cA[c] = selm(mya, m[Cfa<CFA>::col(1, 0)], m[Cfa<CFA>::col(0, 0)]);
+            cB[c] = selm(mya, m[Cfa<CFA>::col(1, 1)], m[Cfa<CFA>::col(0, 1)]);
         }
 
         float a[5], wc[5];
@@ -161,23 +172,21 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
         for (int it = 0; it < 5; it++) {
             const int n = jt * 5 + it;
             const float wt = w[n <= 12 ? n : 24 - n];
-            constexpr int dummy = 0;
-            (void)dummy;
             const int c = (((K + it + 2) >> 2) == cellLo) ? 0 : 1;
-            bool xa;
-            if (it == 0 || it == 4) xa = pA;
-            if (it == 2) xa = !pA;
-            if (it == 1) xa = pB;
-            if (it == 3) xa = !pB;
-            const float cert = xa ? cB[c] : cA[c];
+            uint32_t mxa;
+            if (it == 0 || it == 4) mxa = mA;
+            if (it == 2) mxa = ~mA;
+            if (it == 1) mxa = mB;
+            if (it == 3) mxa = ~mB;
+            const float cert = selm(mxa, cB[c], cA[c]);
             wc[it] = wt * cert;
             a[it] = v[it] * wc[it];
         }
         // x classes relative to P: columns 0,4 -> 0; 2 -> 1; 1 -> bx; 3 -> !bx
-        const float rowS0 = (a[0] + a[4]) + (bx ? a[3] : a[1]);
-        const float rowS1 = a[2] + (bx ? a[1] : a[3]);
-        const float rowW0 = (wc[0] + wc[4]) + (bx ? wc[3] : wc[1]);
-        const float rowW1 = wc[2] + (bx ? wc[1] : wc[3]);
+        const float rowS0 = (a[0] + a[4]) + selm(mbx, a[3], a[1]);
+        const float rowS1 = a[2] + selm(mbx, a[1], a[3]);
+        const float rowW0 = (wc[0] + wc[4]) + selm(mbx, wc[3], wc[1]);
+        const float rowW1 = wc[2] + selm(mbx, wc[1], wc[3]);
         if (jt == 0 || jt == 4) {
             S[0][0] += rowS0;
             S[0][1] += rowS1;
@@ -203,17 +212,17 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
     // y classes relative to Q: rows 0,4 -> 0; 2 -> 1; 1 -> by; 3 -> !by
 #pragma unroll
     for (int xc = 0; xc < 2; xc++) {
-        S[0][xc] += by ? r3S[xc] : r1S[xc];
-        S[1][xc] += by ? r1S[xc] : r3S[xc];
-        W[0][xc] += by ? r3W[xc] : r1W[xc];
-        W[1][xc] += by ? r1W[xc] : r3W[xc];
+        S[0][xc] += selm(mby, r3S[xc], r1S[xc]);
+        S[1][xc] += selm(mby, r1S[xc], r3S[xc]);
+        W[0][xc] += selm(mby, r3W[xc], r1W[xc]);
+        W[1][xc] += selm(mby, r1W[xc], r3W[xc]);
     }
 
     // relative class (yc, xc) sits at CFA position (yc ^ Q, xc ^ P)
     auto at_pos = [&](const float(&T)[2][2], int yp, int xp) {
-        const float q0 = P ? T[yp][xp ^ 1] : T[yp][xp];          // Q == 0
-        const float q1 = P ? T[yp ^ 1][xp ^ 1] : T[yp ^ 1][xp];  // Q == 1
-        return Q ? q1 : q0;
+        const float q0 = selm(mP, T[yp][xp ^ 1], T[yp][xp]);          // Q == 0
+        const float q1 = selm(mP, T[yp ^ 1][xp ^ 1], T[yp ^ 1][xp]);  // Q == 1
+        return selm(mQ, q1, q0);
     };
     float chS[3] = {0, 0, 0}, chW[3] = {0, 0, 0};
     constexpr int nG = Cfa<CFA>::count(MFSR_GREEN);
@@ -514,9 +523,162 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
     pW[2] = make_float4(accW[8], accW[9], accW[10], accW[11]);
 }
 
+// ---- LDS tile + accumulator segments staged by LDS-DMA ---------------------------------
+template <int CFA>
+__global__ void __launch_bounds__(256, TILE_WAVES)
+    k_accumulate2xTileDma(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
+                       const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
+                       StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
+{
+    __shared__ float4 sK[3][TILE_COLS];
+    __shared__ float2 sF[3][TILE_COLS];
+    __shared__ float4 sM[3][TILE_COLS];
+    // accumulator staging: per wave and plane-set the wave's 3 KiB row segment, in memory order
+    __shared__ __attribute__((aligned(16))) float4 sAcc[4][2][192];
+    const int lx = threadIdx.x, ly = threadIdx.y;
+    const int tx = blockIdx.x * 64 + lx;
+    const int Y = blockIdx.y * 4 + ly;
+    const int hrW = 2 * dimX, hrH = 2 * dimY;
+    const int X0 = 4 * tx;
+    const int fw = kernelParam.width, fh = kernelParam.height;  // == hrW/4, hrH/4 (checked on the host)
+    const int mw = dimX / 2, mh = dimY / 2;                       // certainty mask size
+    {
+        const int t = ly * 64 + lx;
+        if (t < 3 * TILE_COLS) {
+            const int r = t / TILE_COLS, c = t - r * TILE_COLS;
+            const int gy = (int)blockIdx.y - 1 + r, gx = (int)blockIdx.x * 64 - 1 + c;
+            const int fy = clampi(gy, 0, fh - 1), fx = clampi(gx, 0, fw - 1);
+            sK[r][c] = row_ptr((const float4*)kernelParam.ptr, kernelParam.pitch, fy)[fx];
+            sF[r][c] = row_ptr((const float2*)shifts.ptr, shifts.pitch, fy)[fx];
+            const float4 m = row_ptr(certaintyMask, strideMask, clampi(gy, 0, mh - 1))[clampi(gx, 0, mw - 1)];
+            sM[r][c] = make_float4(sane(m.x), sane(m.y), sane(m.z), 0.0f);
+        }
+    }
+    // asynchronous global -> LDS copy of both accumulator segments (no VGPRs, contiguous 1 KiB per
+    // instruction); consumed only after the tap arithmetic
+    const bool rowLive = Y >= 1 && Y < hrH - 1;
+    const size_t rowBytes = (size_t)hrW * 12;
+    const size_t segByte = (size_t)blockIdx.x * 3072;
+    char* gP = (char*)imgOut + (size_t)Y * strideOut + segByte;
+    char* gW = (char*)totalWeights + (size_t)Y * strideOut + segByte;
+    if (rowLive) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const size_t off = (size_t)(j * 64 + lx) * 16;
+            if (segByte + off + 16 <= rowBytes) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gP + off),
+                                                 (__attribute__((address_space(3))) void*)&sAcc[ly][0][j * 64], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW + off),
+                                                 (__attribute__((address_space(3))) void*)&sAcc[ly][1][j * 64], 16, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    if (!rowLive) return;
+    const bool stripLive = X0 < hrW;
+
+    // field row: the same float path as tex_coord; LDS row predicted from ly and verified
+    const float posY = ((float)Y + 0.5f) / (float)hrH;
+    float yB = posY * (float)fh - 0.5f;
+    if (!finitef(yB)) yB = 0.0f;
+    const float fyf = floorf(yB);
+    const float b = yB - fyf;
+    const int fr = ly < 2 ? 0 : 1;  // LDS row of texel row j0 = floor(yB)
+    bool safe = stripLive && tx >= 1 && X0 + 5 <= hrW - 1 && Y >= 2 && Y + 2 <= hrH - 1;
+    safe = safe && (f2i(fyf) == (int)blockIdx.y - 1 + fr) && f2i(fyf) >= 0 && f2i(fyf) + 1 <= fh - 1;
+
+    int sx[4], sy[4];
+    float av[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float posX = ((float)(X0 + k) + 0.5f) / (float)hrW;
+        float xB = posX * (float)fw - 0.5f;
+        if (!finitef(xB)) xB = 0.0f;
+        const float fxf = floorf(xB);
+        av[k] = xB - fxf;
+        const int ci = k < 2 ? 0 : 1;
+        safe = safe && (f2i(fxf) == tx - 1 + ci) && (tx + ci <= fw - 1);
+        const float2 t00 = sF[fr][lx + ci], t10 = sF[fr][lx + ci + 1], t01 = sF[fr + 1][lx + ci], t11 = sF[fr + 1][lx + ci + 1];
+        const float ux = lerp4(t00.x, t10.x, t01.x, t11.x, av[k], b);
+        const float uy = lerp4(t00.y, t10.y, t01.y, t11.y, av[k], b);
+        sx[k] = f2i(roundf(ux * 2.0f));
+        sy[k] = f2i(roundf(uy * 2.0f));
+        const int qx = X0 + k + sx[k] - 2, qy = Y + sy[k] - 2;
+        safe = safe && qx >= 0 && ((qx + 4) >> 1) <= dimX - 1 && qy >= 0 && ((qy + 4) >> 1) <= dimY - 1;
+        safe = safe && sx[k] > -(1 << 20) && sx[k] < (1 << 20) && sy[k] > -(1 << 20) && sy[k] < (1 << 20);
+    }
+    auto kfetch = [&](int k, float& kx, float& ky, float& kz) {
+        const int ci = k < 2 ? 0 : 1;
+        const float4 t00 = sK[fr][lx + ci], t10 = sK[fr][lx + ci + 1], t01 = sK[fr + 1][lx + ci], t11 = sK[fr + 1][lx + ci + 1];
+        kx = lerp4(t00.x, t10.x, t01.x, t11.x, av[k], b);
+        ky = lerp4(t00.y, t10.y, t01.y, t11.y, av[k], b);
+        kz = lerp4(t00.z, t10.z, t01.z, t11.z, av[k], b);
+    };
+    float kxa[4], kya[4], kza[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        kfetch(k, kxa[k], kya[k], kza[k]);
+        safe = safe && psd_ok(kxa[k], kya[k], kza[k]);
+    }
+    float accP[12], accW[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) accP[i] = accW[i] = 0.0f;
+    float* myP = (float*)&sAcc[ly][0][0] + lx * 12;  // this lane's 4 pixels x 3 channels inside the staged segment
+    float* myW = (float*)&sAcc[ly][1][0] + lx * 12;
+    if (safe) {
+    // certainty: LDS row of the mask row that tap row jt reads = ((ly + jt - 2) >> 2) + 1; column lx + cell
+    auto mval = [&](int jt, int cell, int ch) {
+        const int mr = ((ly + jt - 2) >> 2) + 1;
+        const float* p = (const float*)&sM[mr][lx + cell];
+        return p[ch];
+    };
+    strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
+    strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
+    strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
+    strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
+
+    }
+    // staged accumulators must have landed before anyone reads them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (safe) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float4 a = ((float4*)myP)[j], c = ((float4*)myW)[j];
+            a.x += accP[4 * j + 0]; a.y += accP[4 * j + 1]; a.z += accP[4 * j + 2]; a.w += accP[4 * j + 3];
+            c.x += accW[4 * j + 0]; c.y += accW[4 * j + 1]; c.z += accW[4 * j + 2]; c.w += accW[4 * j + 3];
+            ((float4*)myP)[j] = a;
+            ((float4*)myW)[j] = c;
+        }
+    } else if (stripLive) {
+        // border / wild-flow strips: the straight per-pixel arithmetic on the staged values
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            const int X = X0 + k;
+            if (X >= 1 && X < hrW - 1) {
+                pix3 px = {myP[3 * k], myP[3 * k + 1], myP[3 * k + 2]};
+                pix3 tw = {myW[3 * k], myW[3 * k + 1], myW[3 * k + 2]};
+                accumulate_pixel_core<GEOM_FULL, true>(X, Y, raw, certaintyMask, kernelParam, shifts, glv, dimX, dimY, 2,
+                                                       strideMask, cfaPacked, px, tw);
+                myP[3 * k] = px.x; myP[3 * k + 1] = px.y; myP[3 * k + 2] = px.z;
+                myW[3 * k] = tw.x; myW[3 * k + 1] = tw.y; myW[3 * k + 2] = tw.z;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // write the segment back in memory order: contiguous 1 KiB per store instruction
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const size_t off = (size_t)(j * 64 + lx) * 16;
+        if (segByte + off + 16 <= rowBytes) {
+            *(float4*)(gP + off) = sAcc[ly][0][j * 64 + lx];
+            *(float4*)(gW + off) = sAcc[ly][1][j * 64 + lx];
+        }
+    }
+}
+
 constexpr int pack_cfa(int c00, int c01, int c10, int c11) { return c00 | (c01 << 2) | (c10 << 4) | (c11 << 6); }
 
-bool g_strip_use_tile = true;  // MFSR_STRIP_TILE=0 in the environment selects the register-only strip kernel
+int g_strip_use_tile = 2;  // MFSR_STRIP_TILE: 0 register-only strip kernel, 1 LDS tile, 2 LDS tile + LDS-DMA accumulators
 
 template <int CFA>
 void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pix3* imgOut, pix3* tw, const float4* mask,
@@ -526,7 +688,11 @@ void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pi
     const int hrW = 2 * dimX, hrH = 2 * dimY;
     const bool same = kp.width == sh.width && kp.height == sh.height;
     if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4 && (dimX % 4) == 0 && (dimY % 4) == 0 &&
-        g_strip_use_tile)
+        g_strip_use_tile == 2)
+        hipLaunchKernelGGL((k_accumulate2xTileDma<CFA>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
+                           dimY, strideOut, strideMask, cfaPacked);
+    else if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4 && (dimX % 4) == 0 && (dimY % 4) == 0 &&
+             g_strip_use_tile == 1)
         hipLaunchKernelGGL((k_accumulate2xTile<CFA>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX, dimY,
                            strideOut, strideMask, cfaPacked);
     else if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4)
@@ -551,7 +717,7 @@ int mfsr_try_launch_accumulate2x_strip(const uint16_t* dataIn, mfsr_float3* imgO
 {
     static const bool env_read = [] {
         const char* e = getenv("MFSR_STRIP_TILE");
-        if (e && e[0] == '0') g_strip_use_tile = false;
+        if (e && e[0] >= '0' && e[0] <= '2') g_strip_use_tile = e[0] - '0';
         return true;
     }();
     (void)env_read;
