@@ -249,6 +249,44 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
     }
 }
 
+// Frame margin (HR pixels) that the strip/tile kernels leave to k_accumulateMargin: taps of
+// pixels this close to the frame border can be clamped, which the fast path does not handle.
+// Handling them in a separate small launch keeps the fast kernels free of divergent border
+// waves (a wave with one border strip used to execute both paths: +12 % VALU instructions).
+#define STRIP_MARGIN 16
+
+__global__ void __launch_bounds__(256)
+    k_accumulateMargin(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
+                       const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
+                       int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
+{
+    const int hrW = 2 * dimX, hrH = 2 * dimY, M = STRIP_MARGIN;
+    const int rowLen = hrW - 2;                    // x in [1, hrW-1)
+    const int nTop = (M - 1) * rowLen;             // y in [1, M)
+    const int nBot = (M - 1) * rowLen;             // y in [hrH-M, hrH-1)
+    const int sideLen = 2 * (M - 1);               // x in [1, M) and [hrW-M, hrW-1)
+    const int nSide = (hrH - 2 * M) * sideLen;     // y in [M, hrH-M)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int x, y;
+    if (idx < nTop) {
+        y = 1 + idx / rowLen;
+        x = 1 + idx % rowLen;
+    } else if (idx < nTop + nBot) {
+        const int r = idx - nTop;
+        y = hrH - M + r / rowLen;
+        x = 1 + r % rowLen;
+    } else if (idx < nTop + nBot + nSide) {
+        const int r = idx - nTop - nBot;
+        y = M + r / sideLen;
+        const int c = r % sideLen;
+        x = c < M - 1 ? 1 + c : hrW - M + (c - (M - 1));
+    } else {
+        return;
+    }
+    accumulate_pixel_generic<GEOM_FULL, true>(x, y, raw, imgOut, totalWeights, certaintyMask, kernelParam, shifts, glv, dimX,
+                                              dimY, 2, strideOut, strideMask, cfaPacked);
+}
+
 // FR = HR pixels per field texel along each axis (4: fields at LR/2, the Bayer
 // pipeline; 2: fields at LR, the monochrome pipeline; 0: any size, per-pixel fetch).
 template <int CFA, int FR>
@@ -261,13 +299,13 @@ __global__ void __launch_bounds__(256)
     const int Y = blockIdx.y * 4 + threadIdx.y;
     const int hrW = 2 * dimX, hrH = 2 * dimY;
     const int X0 = 4 * tx;
-    if (X0 >= hrW || Y < 1 || Y >= hrH - 1) return;
+    if (X0 < STRIP_MARGIN || X0 >= hrW - STRIP_MARGIN || Y < STRIP_MARGIN || Y >= hrH - STRIP_MARGIN) return;
 
     const float posY = ((float)Y + 0.5f) / (float)hrH;
     int sx[4], sy[4];
     float kx[4], ky[4], kz[4];
     // a strip is "safe" when no tap of its four pixels is clamped at the frame border
-    bool safe = tx >= 1 && X0 + 5 <= hrW - 1 && Y >= 2 && Y + 2 <= hrH - 1;
+    bool safe = true;  // (the frame margin is handled by k_accumulateMargin)
     if (FR == 0) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -434,7 +472,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
         }
     }
     __syncthreads();
-    if (X0 >= hrW || Y < 1 || Y >= hrH - 1) return;
+    if (X0 < STRIP_MARGIN || X0 >= hrW - STRIP_MARGIN || Y < STRIP_MARGIN || Y >= hrH - STRIP_MARGIN) return;
 
     // field row: the same float path as tex_coord; LDS row predicted from ly and verified
     const float posY = ((float)Y + 0.5f) / (float)hrH;
@@ -443,7 +481,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
     const float fyf = floorf(yB);
     const float b = yB - fyf;
     const int fr = ly < 2 ? 0 : 1;  // LDS row of texel row j0 = floor(yB)
-    bool safe = tx >= 1 && X0 + 5 <= hrW - 1 && Y >= 2 && Y + 2 <= hrH - 1;
+    bool safe = true;  // (the frame margin is handled by k_accumulateMargin)
     safe = safe && (f2i(fyf) == (int)blockIdx.y - 1 + fr) && f2i(fyf) >= 0 && f2i(fyf) + 1 <= fh - 1;
 
     int sx[4], sy[4];
@@ -556,7 +594,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
     }
     // asynchronous global -> LDS copy of both accumulator segments (no VGPRs, contiguous 1 KiB per
     // instruction); consumed only after the tap arithmetic
-    const bool rowLive = Y >= 1 && Y < hrH - 1;
+    const bool rowLive = Y >= STRIP_MARGIN && Y < hrH - STRIP_MARGIN;
     const size_t rowBytes = (size_t)hrW * 12;
     const size_t segByte = (size_t)blockIdx.x * 3072;
     char* gP = (char*)imgOut + (size_t)Y * strideOut + segByte;
@@ -575,7 +613,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
     }
     __syncthreads();
     if (!rowLive) return;
-    const bool stripLive = X0 < hrW;
+    const bool stripLive = X0 >= STRIP_MARGIN && X0 < hrW - STRIP_MARGIN;
 
     // field row: the same float path as tex_coord; LDS row predicted from ly and verified
     const float posY = ((float)Y + 0.5f) / (float)hrH;
@@ -584,7 +622,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
     const float fyf = floorf(yB);
     const float b = yB - fyf;
     const int fr = ly < 2 ? 0 : 1;  // LDS row of texel row j0 = floor(yB)
-    bool safe = stripLive && tx >= 1 && X0 + 5 <= hrW - 1 && Y >= 2 && Y + 2 <= hrH - 1;
+    bool safe = stripLive;  // (the frame margin is handled by k_accumulateMargin)
     safe = safe && (f2i(fyf) == (int)blockIdx.y - 1 + fr) && f2i(fyf) >= 0 && f2i(fyf) + 1 <= fh - 1;
 
     int sx[4], sy[4];
@@ -678,7 +716,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
 
 constexpr int pack_cfa(int c00, int c01, int c10, int c11) { return c00 | (c01 << 2) | (c10 << 4) | (c11 << 6); }
 
-int g_strip_use_tile = 2;  // MFSR_STRIP_TILE: 0 register-only strip kernel, 1 LDS tile, 2 LDS tile + LDS-DMA accumulators
+int g_strip_use_tile = 1;  // MFSR_STRIP_TILE: 0 register-only strip kernel, 1 LDS tile, 2 LDS tile + LDS-DMA accumulators
 
 template <int CFA>
 void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pix3* imgOut, pix3* tw, const float4* mask,
@@ -728,7 +766,7 @@ int mfsr_try_launch_accumulate2x_strip(const uint16_t* dataIn, mfsr_float3* imgO
     const int packed2 = pack_cfa(cfa[0], cfa[1], cfa[2], cfa[3]);
     // layout requirements of the vectorised accumulator access
     if ((dimX & 1) || ((uintptr_t)imgOut & 15) || ((uintptr_t)totalWeights & 15) || (strideOut & 15)) return 0;
-    if (dimX < 16 || dimY < 8) return 0;
+    if (dimX < 2 * STRIP_MARGIN || dimY < 2 * STRIP_MARGIN) return 0;
     Levels3 glv;
     StripLevels lv;
     const float wl[3] = {whiteLevel.x, whiteLevel.y, whiteLevel.z}, bl[3] = {blackLevel.x, blackLevel.y, blackLevel.z};
@@ -745,10 +783,17 @@ int mfsr_try_launch_accumulate2x_strip(const uint16_t* dataIn, mfsr_float3* imgO
     pix3* pT = (pix3*)totalWeights;
     const float4* pM = (const float4*)certaintyMask;
     const int cp = mfsr_cfa_packed();
+    auto launch_margin = [&]() {
+        const int M = STRIP_MARGIN;
+        const long long n = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
+        hipLaunchKernelGGL(k_accumulateMargin, dim3(mfsr_cdiv(n, 256)), dim3(256), 0, st, dataIn, pI, pT, pM, kernelParam,
+                           shifts, glv, dimX, dimY, strideOut, strideMask, cp);
+    };
 #define STRIP_CASE(a, b, c, d)                                                                                         \
     case pack_cfa(a, b, c, d):                                                                                         \
         launch_strip<pack_cfa(a, b, c, d)>(grid, block, st, dataIn, pI, pT, pM, kernelParam, shifts, glv, lv, dimX, dimY, \
                                           strideOut, strideMask, cp);                                                  \
+        launch_margin();                                                                                               \
         return 1;
     switch (packed2) {
         STRIP_CASE(MFSR_RED, MFSR_GREEN, MFSR_GREEN, MFSR_BLUE)   // RGGB
