@@ -406,11 +406,10 @@ extern "C" int mfsr_fill_f32(float* dst, size_t count, float value, mfsr_stream_
 #define ST_TY 8
 __device__ __forceinline__ int mirror_index(int i, int n)
 {
-    // reflect about the edges (…2 1 0 | 0 1 2 … n-1 | n-1 n-2 …): CUDA mirror mode at texel centres
-    const int period = 2 * n;
-    int k = i % period;
-    if (k < 0) k += period;
-    return (k < n) ? k : period - 1 - k;
+    // reflect about the edges (…2 1 0 | 0 1 2 … n-1 | n-1 n-2 …): CUDA mirror mode at texel centres;
+    // valid for -n <= i < 2n (the 2-px halo), no integer division
+    i = i < 0 ? -1 - i : i;
+    return i >= n ? 2 * n - 1 - i : i;
 }
 
 __global__ void __launch_bounds__(ST_TX* ST_TY) k_structureTensorFused(const float* __restrict__ img, int imgPitch,
@@ -448,7 +447,7 @@ __global__ void __launch_bounds__(ST_TX* ST_TY) k_structureTensorFused(const flo
 extern "C" int mfsr_structureTensorFused(const float* img, int imgPitch, mfsr_float3* outImg, int outPitch, int width,
                                          int height, mfsr_stream_t stream)
 {
-    MFSR_REQUIRE(img && outImg && width > 0 && height > 0 && (long long)imgPitch >= 4LL * width &&
+    MFSR_REQUIRE(img && outImg && width >= 4 && height >= 4 && (long long)imgPitch >= 4LL * width &&
                  (long long)outPitch >= 12LL * width && (imgPitch & 3) == 0 && (outPitch & 3) == 0);
     dim3 block(ST_TX, ST_TY), grid(mfsr_cdiv(width, ST_TX), mfsr_cdiv(height, ST_TY));
     hipLaunchKernelGGL(k_structureTensorFused, grid, block, 0, mfsr_s(stream), img, imgPitch, (pix3*)outImg, outPitch,

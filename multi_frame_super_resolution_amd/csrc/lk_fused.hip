@@ -34,19 +34,23 @@
 #define LK_TY 16
 #define LK_THREADS (LK_TX * LK_TY)
 
+// reflection about the image edges for -n <= i < 2n (the tile halo never reaches further):
+// ... 1 0 | 0 1 ... n-1 | n-1 n-2 ...   (no integer division)
 __device__ __forceinline__ int lk_mirror_index(int i, int n)
 {
-    const int period = 2 * n;
-    int k = i % period;
-    if (k < 0) k += period;
-    return (k < n) ? k : period - 1 - k;
+    i = i < 0 ? -1 - i : i;
+    return i >= n ? 2 * n - 1 - i : i;
 }
 
+// HT > 0: half window size known at compile time (tile geometry becomes constant, so the
+// index arithmetic of the staging loops needs no runtime integer division); HT == 0: runtime h.
+template <int HT>
 __global__ void __launch_bounds__(LK_THREADS)
     k_lkIterationFused(const float2* __restrict__ shiftsIn, float2* __restrict__ shiftsOut, int pitchShift,
                        const float* __restrict__ refImg, const float* __restrict__ movedImg, int pitchImg, int width,
-                       int height, int h, float minDet)
+                       int height, int hRuntime, float minDet)
 {
+    const int h = HT > 0 ? HT : hRuntime;
     extern __shared__ __attribute__((aligned(16))) float s_lk[];
     const int BW = LK_TX + 2 * h + 4, BH = LK_TY + 2 * h + 4;  // warped / ref region
     const int AW = LK_TX + 2 * h, AH = LK_TY + 2 * h;          // derivative region
@@ -168,14 +172,28 @@ extern "C" int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            MFSR_HIP_TRY(hipFuncSetAttribute((const void*)k_lkIterationFused, hipFuncAttributeMaxDynamicSharedMemorySize,
+            MFSR_HIP_TRY(hipFuncSetAttribute((const void*)k_lkIterationFused<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             160 * 1024));
+            MFSR_HIP_TRY(hipFuncSetAttribute((const void*)k_lkIterationFused<7>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              160 * 1024));
             attr_set = true;
         }
     }
     if (lds > 160 * 1024) return MFSR_E_UNSUPPORTED;
+    MFSR_REQUIRE(width >= LK_TX + 2 * h + 4 && height >= LK_TY + 2 * h + 4);  // reflection range of the halo
     dim3 block(LK_TX, LK_TY), grid(mfsr_cdiv(width, LK_TX), mfsr_cdiv(height, LK_TY));
-    hipLaunchKernelGGL(k_lkIterationFused, grid, block, lds, mfsr_s(stream), (const float2*)shiftsIn, (float2*)shiftsOut,
-                       pitchShift, refImg, movedImg, pitchImg, width, height, h, minDet);
+#define LK_LAUNCH(HT)                                                                                                  \
+    hipLaunchKernelGGL(k_lkIterationFused<HT>, grid, block, lds, mfsr_s(stream), (const float2*)shiftsIn,              \
+                       (float2*)shiftsOut, pitchShift, refImg, movedImg, pitchImg, width, height, h, minDet)
+    switch (h) {
+        case 1: LK_LAUNCH(1); break;
+        case 2: LK_LAUNCH(2); break;
+        case 3: LK_LAUNCH(3); break;
+        case 4: LK_LAUNCH(4); break;
+        case 5: LK_LAUNCH(5); break;
+        case 7: LK_LAUNCH(7); break;
+        default: LK_LAUNCH(0); break;
+    }
+#undef LK_LAUNCH
     return mfsr_launch_status("lucasKanadeIterationFused");
 }
