@@ -90,6 +90,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=4)
     ap.add_argument("--unfused", action="store_true", help="one launch per reference kernel (A/B against the fused path)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N>1: run the RCCL exchange of burst i on the compute stream instead of overlapping it with the "
+                         "align+fuse of burst i+1")
+    ap.add_argument("--force-pipelined", action="store_true", help="use the two-context pipelined step loop even at N=1 (test)")
     args = ap.parse_args()
 
     import torch
@@ -133,11 +137,42 @@ def main():
     del shard
     torch.cuda.synchronize()
 
+    # Steps are independent bursts, so at N>1 the exchange (reduce-scatter, stripe finish, gather)
+    # of burst i runs on a side stream while the compute stream already aligns and fuses burst
+    # i+1 into a second burst context (own workspace + accumulators): collectives overlap compute.
+    pipelined = (world > 1 and not args.no_overlap) or args.force_pipelined
+    pipes = [pipe]
+    step_no = [0]
+    if pipelined:
+        pipes.append(BurstPipeline(cfg, dev))
+        side = torch.cuda.Stream(device=dev)
+        ev_acc = [torch.cuda.Event() for _ in pipes]    # accumulate of the burst in context j done (compute stream)
+        ev_done = [torch.cuda.Event() for _ in pipes]   # exchange + finish of context j done (side stream)
+        used = [False for _ in pipes]
+
     def step():
-        if world > 1:
-            mdist.accumulate_local(pipe, frames, rank, world, n_frames)
-            return mdist.exchange_and_finish(pipe, args.exchange)
-        return mdist.process_burst(pipe, frames, n_frames=n_frames)
+        if not pipelined:
+            if world > 1:
+                mdist.accumulate_local(pipe, frames, rank, world, n_frames)
+                return mdist.exchange_and_finish(pipe, args.exchange)
+            return mdist.process_burst(pipe, frames, n_frames=n_frames)
+        j = step_no[0] % 2
+        step_no[0] += 1
+        p = pipes[j]
+        main = torch.cuda.current_stream()
+        if used[j]:
+            main.wait_event(ev_done[j])                 # context j is free again
+        mdist.accumulate_local(p, frames, rank, world, n_frames)
+        ev_acc[j].record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_acc[j])
+            if world > 1:
+                out = mdist.exchange_and_finish(p, args.exchange)
+            else:
+                _, out = p.finish(want_float=False, want_u16=True)
+            ev_done[j].record(side)
+        used[j] = True
+        return out
 
     def barrier():
         if world > 1:
@@ -149,15 +184,20 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    pipe.L.burst_timing(pipe._h, 1)
+    for q in pipes:
+        q.L.burst_timing(q._h, 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
     tot_ms, launches = ctypes.c_double(0), ctypes.c_int(0)
-    pipe.L.burst_timing_read(pipe._h, ctypes.byref(tot_ms), ctypes.byref(launches))
-    pipe.L.burst_timing(pipe._h, 0)
+    for q in pipes:
+        t_ms, n_l = ctypes.c_double(0), ctypes.c_int(0)
+        q.L.burst_timing_read(q._h, ctypes.byref(t_ms), ctypes.byref(n_l))
+        q.L.burst_timing(q._h, 0)
+        tot_ms.value += t_ms.value
+        launches.value += n_l.value
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -196,7 +236,8 @@ def main():
                 "frames_per_gpu": len(mine),
                 "burst_frames": n_frames,
                 "output_mpix_per_s": round(s * s * W * H * args.steps / dt / 1e6, 2),
-                "parallelism": "1 GPU" if world == 1 else f"frame-shard x{world} + RCCL {args.exchange} of HR accumulators",
+                "parallelism": "1 GPU" if world == 1 else f"frame-shard x{world} + RCCL {args.exchange} of HR accumulators"
+                               + (" overlapped with the next burst's compute" if pipelined else ""),
                 "kernels": "unfused (one launch per reference kernel)" if args.unfused else "fused",
             },
             "roofline": {
@@ -218,7 +259,8 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
 
-    pipe.close()
+    for q in pipes:
+        q.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
