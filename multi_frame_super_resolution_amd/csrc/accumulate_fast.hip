@@ -433,6 +433,187 @@ __global__ void __launch_bounds__(256)
     pW[2] = make_float4(accW[8], accW[9], accW[10], accW[11]);
 }
 
+// ---- uniform-shift strips -----------------------------------------------------------------
+// The flow is smooth, so nearly every strip has ONE rounded shift (sx, sy) for its four pixels.
+// Then the strip is a rigid 4x1 block in the raw frame and everything that strip_pixel resolves
+// per lane and per tap with selects is a compile-time function of two bits, SIG = sx & 1 and
+// BY = (Y + sy) & 1 (the kernel dispatches on them; in a wave whose strips agree only one of the
+// four bodies runs):
+//  * the four pixels share 3 x (4 + SIG) raw sites: 12..15 loads per strip instead of 36;
+//  * which site a tap hits, which certainty cell it reads and which CFA-position class it adds
+//    to are static, so the per-tap work is one multiply, one fma and one add;
+//  * the certainty of (site colour, cell) is resolved once per strip and tap row (E[][]) with
+//    the two per-lane CFA phase masks, instead of per pixel and per tap;
+//  * taps of a pixel that land on the same site and read the same cell add their weights first;
+//  * the 12 non-trivial exponents are built from pre-scaled sums (2 adds each, no multiply).
+// The sums are re-associated once more against strip_pixel (and use fma), so results agree to
+// ~1e-6 relative, as between strip_pixel and the straight kernel.
+template <int SIG>
+struct UGeom {
+    static constexpr int NCOL = SIG ? 5 : 4;  // raw site columns the strip touches
+    static constexpr int NE = SIG ? 7 : 4;    // distinct (site column, certainty cell) pairs per tap row
+    // m = K + it (0..7): HR tap column relative to X0 - 2
+    static constexpr int site(int m) { return (m + SIG) >> 1; }
+    static constexpr int cell(int m) { return (m + 2) >> 2; }  // 0..2 <-> mask column tx-1 .. tx+1
+    static constexpr int eid(int m)
+    {
+        if (!SIG) return m >> 1;
+        constexpr int t[8] = {0, 1, 2, 3, 3, 4, 5, 6};
+        return t[m];
+    }
+    static constexpr int rep(int e)  // a representative m of pair e
+    {
+        for (int m = 0; m < 8; m++)
+            if (eid(m) == e) return m;
+        return 0;
+    }
+};
+
+template <int CFA, int SIG, int BY, typename MRowF>
+__device__ __forceinline__ void strip_uniform(int X0, int Y, int sx, int sy, const float (&kxa)[4], const float (&kya)[4],
+                                              const float (&kza)[4], const uint16_t* __restrict__ raw, int dimX,
+                                              MRowF mrow, const StripLevels& lv, float* accP, float* accW)
+{
+    using G = UGeom<SIG>;
+    const int qx0 = X0 + sx - 2, qy = Y + sy - 2;  // qx0 & 1 == SIG, qy & 1 == BY
+    const int xb = qx0 >> 1, y0 = qy >> 1;
+    const uint32_t mP = 0u - (uint32_t)(xb & 1), mQ = 0u - (uint32_t)(y0 & 1);
+    constexpr bool mono = Cfa<CFA>::count(MFSR_GREEN) == 4;
+
+    float s[3][G::NCOL];
+    {
+        const uint16_t* r = raw + (size_t)y0 * dimX + xb;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int c = 0; c < G::NCOL; c++) s[j][c] = (float)r[j * dimX + c];
+    }
+
+    // certainty of the colour at site (row of tap row jt, column site(m)) in cell(m)
+    float E[5][G::NE];
+#pragma unroll
+    for (int jt = 0; jt < 5; jt++) {
+        const int yc = ((BY + jt) >> 1) & 1;  // site row parity relative to Q
+        float c0[3], c1[3];                   // per cell: certainty at absolute x parity 0 / 1 on this site row
+#pragma unroll
+        for (int cl = 0; cl < 3; cl++) {
+            bool used = false;
+#pragma unroll
+            for (int m = 0; m < 8; m++) used = used || G::cell(m) == cl;
+            if (!used) continue;
+            const float4 q = mrow(jt, cl);
+            const float mm[3] = {q.x, q.y, q.z};
+            if (mono) {
+                c0[cl] = c1[cl] = mm[MFSR_GREEN];
+            } else if (yc == 0) {
+                c0[cl] = selm(mQ, mm[Cfa<CFA>::col(1, 0)], mm[Cfa<CFA>::col(0, 0)]);
+                c1[cl] = selm(mQ, mm[Cfa<CFA>::col(1, 1)], mm[Cfa<CFA>::col(0, 1)]);
+            } else {
+                c0[cl] = selm(mQ, mm[Cfa<CFA>::col(0, 0)], mm[Cfa<CFA>::col(1, 0)]);
+                c1[cl] = selm(mQ, mm[Cfa<CFA>::col(0, 1)], mm[Cfa<CFA>::col(1, 1)]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < G::NE; e++) {
+            const int m = G::rep(e), cl = G::cell(m), xc = G::site(m) & 1;
+            if (mono)
+                E[jt][e] = c0[cl];
+            else
+                E[jt][e] = xc == 0 ? selm(mP, c1[cl], c0[cl]) : selm(mP, c0[cl], c1[cl]);
+        }
+    }
+
+#pragma unroll
+    for (int K = 0; K < 4; K++) {
+        const int oK = (K + SIG) >> 1, bx = (K + SIG) & 1;
+        // 13 unique weights, n = jt*5+it, w[n] == w[24-n]; exponent pre-scaled by -0.5*log2(e)
+        float w[13];
+        {
+            const float a1 = kxa[K] * -0.72134752044448170368f, b1 = kya[K] * -0.72134752044448170368f;
+            const float c1 = kza[K] * -0.72134752044448170368f;
+            const float a4 = 4.0f * a1, b4 = 4.0f * b1;
+            const float A[3] = {0.0f, a1, a4}, B[3] = {0.0f, b1, b4};
+            float D[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) D[i][j] = (i == 0) ? B[j] : (j == 0 ? A[i] : A[i] + B[j]);
+#pragma unroll
+            for (int n = 0; n < 13; n++) {
+                const int py = n / 5 - 2, px = n % 5 - 2;
+                const int apx = px < 0 ? -px : px, apy = py < 0 ? -py : py;
+                if (n == 12) {
+                    w[n] = 1.0f;
+                } else if (px * py == 0) {
+                    w[n] = __builtin_amdgcn_exp2f(D[apx][apy]);
+                } else {
+                    w[n] = __builtin_amdgcn_exp2f(D[apx][apy] + (float)(2 * px * py) * c1);
+                }
+            }
+        }
+        float S[2][2] = {{0, 0}, {0, 0}}, W[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+        for (int jt = 0; jt < 5; jt++) {
+            const int j = (BY + jt) >> 1, yc = j & 1;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                // taps of this tap row that land on site column oK + i
+                int ita = -1, itb = -1;
+#pragma unroll
+                for (int it = 0; it < 5; it++)
+                    if (((bx + it) >> 1) == i) {
+                        if (ita < 0)
+                            ita = it;
+                        else
+                            itb = it;
+                    }
+                const int c = oK + i, xc = c & 1;
+                const int na = jt * 5 + ita;
+                const float wa = w[na <= 12 ? na : 24 - na];
+                float wc;
+                if (itb < 0) {
+                    wc = wa * E[jt][G::eid(K + ita)];
+                } else {
+                    const int nb = jt * 5 + itb;
+                    const float wb = w[nb <= 12 ? nb : 24 - nb];
+                    if (G::eid(K + ita) == G::eid(K + itb))
+                        wc = (wa + wb) * E[jt][G::eid(K + ita)];
+                    else
+                        wc = __builtin_fmaf(wb, E[jt][G::eid(K + itb)], wa * E[jt][G::eid(K + ita)]);
+                }
+                S[yc][xc] = __builtin_fmaf(s[j][c], wc, S[yc][xc]);
+                W[yc][xc] += wc;
+            }
+        }
+        // relative class (yc, xc) sits at CFA position (yc ^ Q, xc ^ P)
+        auto at_pos = [&](const float(&T)[2][2], int yp, int xp) {
+            const float q0 = selm(mP, T[yp][xp ^ 1], T[yp][xp]);          // Q == 0
+            const float q1 = selm(mP, T[yp ^ 1][xp ^ 1], T[yp ^ 1][xp]);  // Q == 1
+            return selm(mQ, q1, q0);
+        };
+        float chS[3] = {0, 0, 0}, chW[3] = {0, 0, 0};
+        const float totS = (S[0][0] + S[0][1]) + (S[1][0] + S[1][1]);
+        const float totW = (W[0][0] + W[0][1]) + (W[1][0] + W[1][1]);
+        if (mono) {
+            chS[1] = totS;
+            chW[1] = totW;
+        } else {
+            constexpr int pr = Cfa<CFA>::pos_of(MFSR_RED), pb = Cfa<CFA>::pos_of(MFSR_BLUE);
+            chS[0] = at_pos(S, pr >> 1, pr & 1);
+            chW[0] = at_pos(W, pr >> 1, pr & 1);
+            chS[2] = at_pos(S, pb >> 1, pb & 1);
+            chW[2] = at_pos(W, pb >> 1, pb & 1);
+            chS[1] = (totS - chS[0]) - chS[2];
+            chW[1] = (totW - chW[0]) - chW[2];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            accP[3 * K + c] += (chS[c] - lv.black[c] * chW[c]) * lv.invWhite[c];
+            accW[3 * K + c] += chW[c];
+        }
+    }
+}
+
 // ---- LDS-tiled variant (fields at HR/4: the Bayer pipeline) ------------------------------
 // One 64x4 workgroup covers a 256 x 4 HR tile.  The kernel-parameter / flow texels and the
 // certainty texels that the tile touches (3 rows x 66 columns each) are staged once in LDS
@@ -443,7 +624,7 @@ __global__ void __launch_bounds__(256)
 #ifndef TILE_WAVES
 #define TILE_WAVES 4
 #endif
-template <int CFA>
+template <int CFA, bool UNI>
 __global__ void __launch_bounds__(256, TILE_WAVES)
     k_accumulate2xTile(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
                        const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
@@ -548,10 +729,22 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
         const float* p = (const float*)&sM[mr][lx + cell];
         return p[ch];
     };
-    strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
-    strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
-    strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
-    strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
+    auto mrow = [&](int jt, int cell) { return sM[((ly + jt - 2) >> 2) + 1][lx + cell]; };
+    const bool uni = UNI && sx[1] == sx[0] && sx[2] == sx[0] && sx[3] == sx[0] && sy[1] == sy[0] && sy[2] == sy[0] &&
+                     sy[3] == sy[0];
+    if (uni) {
+        switch ((sx[0] & 1) | (((Y + sy[0]) & 1) << 1)) {
+            case 0: strip_uniform<CFA, 0, 0>(X0, Y, sx[0], sy[0], kxa, kya, kza, raw, dimX, mrow, lv, accP, accW); break;
+            case 1: strip_uniform<CFA, 1, 0>(X0, Y, sx[0], sy[0], kxa, kya, kza, raw, dimX, mrow, lv, accP, accW); break;
+            case 2: strip_uniform<CFA, 0, 1>(X0, Y, sx[0], sy[0], kxa, kya, kza, raw, dimX, mrow, lv, accP, accW); break;
+            default: strip_uniform<CFA, 1, 1>(X0, Y, sx[0], sy[0], kxa, kya, kza, raw, dimX, mrow, lv, accP, accW); break;
+        }
+    } else {
+        strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
+        strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
+        strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
+        strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
+    }
 
     pP[0] = make_float4(accP[0], accP[1], accP[2], accP[3]);
     pP[1] = make_float4(accP[4], accP[5], accP[6], accP[7]);
@@ -730,8 +923,12 @@ void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pi
         hipLaunchKernelGGL((k_accumulate2xTileDma<CFA>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
                            dimY, strideOut, strideMask, cfaPacked);
     else if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4 && (dimX % 4) == 0 && (dimY % 4) == 0 &&
+             g_strip_use_tile == 3)
+        hipLaunchKernelGGL((k_accumulate2xTile<CFA, true>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX, dimY,
+                           strideOut, strideMask, cfaPacked);
+    else if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4 && (dimX % 4) == 0 && (dimY % 4) == 0 &&
              g_strip_use_tile == 1)
-        hipLaunchKernelGGL((k_accumulate2xTile<CFA>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX, dimY,
+        hipLaunchKernelGGL((k_accumulate2xTile<CFA, false>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX, dimY,
                            strideOut, strideMask, cfaPacked);
     else if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4)
         hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 4>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
@@ -755,7 +952,7 @@ int mfsr_try_launch_accumulate2x_strip(const uint16_t* dataIn, mfsr_float3* imgO
 {
     static const bool env_read = [] {
         const char* e = getenv("MFSR_STRIP_TILE");
-        if (e && e[0] >= '0' && e[0] <= '2') g_strip_use_tile = e[0] - '0';
+        if (e && e[0] >= '0' && e[0] <= '3') g_strip_use_tile = e[0] - '0';
         return true;
     }();
     (void)env_read;

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Kernel-level timing of mfsr_accumulateSuperResFull (x2, 4K RGGB) with a controllable flow field.
+
+  python tools/fuse_ubench.py [--flow const|smooth|noisy|random] [--iters 20]
+
+const  : one sub-pixel translation (every strip has one rounded shift, every wave one parity)
+smooth : translation + 0.2 deg rotation + mild zoom (parities change along curves)
+noisy  : const + N(0, 0.05 px) per flow texel (worst realistic case: LK noise near a rounding edge)
+random : uniform(-6, 6) per texel (no strip is uniform)
+MFSR_STRIP_TILE selects the kernel variant as in the library."""
+import argparse
+import ctypes
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multi_frame_super_resolution_amd import capi  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--flow", default="const")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--shift", type=float, nargs=2, default=[1.3, -2.6])
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    L = capi.lib()
+    W, H = args.width, args.height
+    hw, hh = 2 * W, 2 * H
+    fw, fh = W // 2, H // 2
+    g = torch.Generator(device=dev).manual_seed(3)
+    raw = torch.randint(256, 3800, (H, W), device=dev, generator=g, dtype=torch.int32).to(torch.int16)
+    img = torch.zeros(hh, hw, 3, device=dev)
+    tw = torch.zeros(hh, hw, 3, device=dev)
+    mask = torch.rand(fh, fw, 4, device=dev, generator=g)
+    # PSD kernel parameters like ComputeKernelParam's: eigenvalues in [0.7, 40], random orientation
+    th = torch.rand(fh, fw, device=dev, generator=g) * math.pi
+    l1 = 0.7 + 2.0 * torch.rand(fh, fw, device=dev, generator=g)
+    l2 = 0.7 + 40.0 * torch.rand(fh, fw, device=dev, generator=g) ** 3
+    c, s = torch.cos(th), torch.sin(th)
+    kp = torch.stack([l1 * c * c + l2 * s * s, l1 * s * s + l2 * c * c, (l1 - l2) * c * s, torch.zeros_like(th)], -1).contiguous()
+    yy, xx = torch.meshgrid(torch.arange(fh, device=dev, dtype=torch.float32),
+                            torch.arange(fw, device=dev, dtype=torch.float32), indexing="ij")
+    ux = torch.full_like(xx, args.shift[0])
+    uy = torch.full_like(xx, args.shift[1])
+    if args.flow == "smooth":
+        a = math.radians(0.2)
+        cx, cy = fw / 2, fh / 2
+        ux = ux + ((xx - cx) * (math.cos(a) * 1.0005 - 1) - (yy - cy) * math.sin(a)) * 2
+        uy = uy + ((xx - cx) * math.sin(a) + (yy - cy) * (math.cos(a) * 1.0005 - 1)) * 2
+    elif args.flow == "noisy":
+        ux = ux + 0.05 * torch.randn(fh, fw, device=dev, generator=g)
+        uy = uy + 0.05 * torch.randn(fh, fw, device=dev, generator=g)
+    elif args.flow == "random":
+        ux = torch.rand(fh, fw, device=dev, generator=g) * 12 - 6
+        uy = torch.rand(fh, fw, device=dev, generator=g) * 12 - 6
+    sh = torch.stack([ux, uy], -1).contiguous()
+    # fraction of strips with one rounded shift (HR-resolution check on a coarse proxy: texel level)
+    r = torch.round(2 * sh)
+    same = ((r[:, 1:] == r[:, :-1]).all(-1)).float().mean().item()
+
+    def tex(t, texel):
+        return capi.Tex2D(t.data_ptr(), t.shape[1] * texel, t.shape[1], t.shape[0])
+
+    white, black = capi.Float3(3839, 3839, 3839), capi.Float3(256, 256, 256)
+    L.set_cfa_pattern((ctypes.c_int * 4)(0, 1, 1, 2))
+
+    def launch():
+        L.accumulateSuperResFull(raw.data_ptr(), img.data_ptr(), tw.data_ptr(), mask.data_ptr(), tex(kp, 16), tex(sh, 8),
+                                 white, black, W, H, 2, hw * 12, fw * 16, None)
+
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.iters
+    nbytes = hw * hh * 48 + W * H * 2 + fw * fh * (16 + 8 + 16)
+    print(f"tile={os.environ.get('MFSR_STRIP_TILE', 'default')} flow={args.flow} texel-neighbour-same={same:.3f} "
+          f"{ms:.4f} ms/launch (incl. margin kernel)  {nbytes / ms / 1e6:.0f} GB/s  checksum={float(tw.sum()):.6e}")
+
+
+if __name__ == "__main__":
+    main()
