@@ -86,18 +86,31 @@ __device__ __forceinline__ float selm(uint32_t m, float a, float b)  // m == ~0u
     return __uint_as_float(__builtin_amdgcn_bitop3_b32(m, __float_as_uint(a), __float_as_uint(b), 0xCA));
 }
 
+// Second formulation of the same pixel: the dynamic part (which raw site a tap lands on) is
+// applied to the WEIGHTS, not to the values.
+//  * site sums: out = sum_sites raw[j][i] * Om[j][i], Om[j][i] = sum of w*certainty over the taps on
+//    site (j,i).  The CFA-position class of a site is static ((j&1, i&1) relative to (Q,P)), so the
+//    value side is 9 fma + 5 add with no selects at all;
+//  * tap columns 1 and 3 change site with the x parity bit: their weights are split once per
+//    pixel into (w & ~mbx, w & mbx) (5 unique weights, plain v_and), tap rows 1 and 3 are split
+//    the same way on the column sums;
+//  * per tap row the certainty is resolved to (even site column, odd site column) x (cell) = at most
+//    four values instead of one select per tap;
+//  * exponents from pre-scaled sums: 2 adds per weight instead of mul+2 adds+mul.
+// ~245 VALU instructions per pixel instead of ~330; sums re-associated again (fma), same tolerance.
 template <int K, int CFA, typename MaskF>
 __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float kx, float ky, float kz,
-                                            const uint16_t* __restrict__ raw, int dimX, MaskF mval,
-                                            const StripLevels& lv, float* accP, float* accW)
+                                             const uint16_t* __restrict__ raw, int dimX, MaskF mval,
+                                             const StripLevels& lv, float* accP, float* accW)
 {
     const int qx = X + sx - 2, qy = Y + sy - 2;
     const int x0 = qx >> 1, y0 = qy >> 1;
-    // lane masks (all ones / zero) of the four parity bits
     const uint32_t mbx = 0u - (uint32_t)(qx & 1), mby = 0u - (uint32_t)(qy & 1);
+    const uint32_t nbx = ~mbx, nby = ~mby;
     const uint32_t mP = 0u - (uint32_t)(x0 & 1), mQ = 0u - (uint32_t)(y0 & 1);
+    constexpr bool mono = Cfa<CFA>::count(MFSR_GREEN) == 4;
+    auto andm = [](uint32_t m, float a) { return __uint_as_float(m & __float_as_uint(a)); };
 
-    // 3x3 raw sites
     float s[3][3];
     {
         const uint16_t* r = raw + (size_t)y0 * dimX + x0;
@@ -107,134 +120,115 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
             for (int i = 0; i < 3; i++) s[j][i] = (float)r[j * dimX + i];
     }
 
-    // 13 unique weights: n = jt*5+it, w[n] == w[24-n]
+    // 13 unique weights, n = jt*5+it, w[n] == w[24-n]; exponents pre-scaled by -0.5*log2(e)
     float w[13];
     {
-        const float Ax[3] = {0.0f, kx, 4.0f * kx};  // px*px*kx, exact
-        const float Cy[3] = {0.0f, ky, 4.0f * ky};  // py*py*ky, exact
+        const float a1 = kx * -0.72134752044448170368f, b1 = ky * -0.72134752044448170368f;
+        const float c1 = kz * -0.72134752044448170368f;
+        const float A[3] = {0.0f, a1, 4.0f * a1}, B[3] = {0.0f, b1, 4.0f * b1};
 #pragma unroll
-        for (int n = 0; n < 13; n++) {
+        for (int n = 0; n < 12; n++) {
             const int py = n / 5 - 2, px = n % 5 - 2;
             const int apx = px < 0 ? -px : px, apy = py < 0 ? -py : py;
-            // (px*px*kx + 2*px*py*kz) + py*py*ky with the reference's two rounded adds (:427)
-            float e = (Ax[apx] + (float)(2 * px * py) * kz) + Cy[apy];
-            float t = e * -0.72134752044448170368f;  // exp(-e/2) = exp2(e * -0.5*log2(e))
-            // the caller admits only positive semi-definite kernel parameters to this path, so
-            // e >= 0 and w = exp2(t) is in [0, 1]: the non-finite rule of :429-430 cannot fire
-            w[n] = __builtin_amdgcn_exp2f(t);
+            const float d = apx == 0 ? B[apy] : (apy == 0 ? A[apx] : A[apx] + B[apy]);
+            w[n] = __builtin_amdgcn_exp2f(px * py == 0 ? d : d + (float)(2 * px * py) * c1);
+        }
+        w[12] = 1.0f;
+    }
+    // tap columns 1 and 3: part that joins the lower / the upper site column
+    float wl[13], wh[13];
+#pragma unroll
+    for (int n = 0; n < 13; n++) {
+        const int it = n % 5;
+        if (it == 1 || it == 3) {
+            wl[n] = andm(nbx, w[n]);
+            wh[n] = andm(mbx, w[n]);
         }
     }
+    // n = 13 (row 2, column 3) mirrors n = 11
+    auto W_ = [&](int jt, int it) { const int n = jt * 5 + it; return w[n <= 12 ? n : 24 - n]; };
+    auto WL = [&](int jt, int it) { const int n = jt * 5 + it; return wl[n <= 12 ? n : 24 - n]; };
+    auto WH = [&](int jt, int it) { const int n = jt * 5 + it; return wh[n <= 12 ? n : 24 - n]; };
 
-    // relative CFA-position class sums [yc][xc]
-    float S[2][2] = {{0, 0}, {0, 0}}, W[2][2] = {{0, 0}, {0, 0}};
-    float r1S[2], r1W[2], r3S[2], r3W[2];
+    const uint32_t mY13 = mQ ^ mby;  // y parity of tap row 1's site row (complement for row 3)
+    constexpr int cellLo = (K + 0 + 2) >> 2;
+    auto cidx = [](int it) { return (((K + it + 2) >> 2) == ((K + 2) >> 2)) ? 0 : 1; };
 
-    const uint32_t mA = mP;        // x parity of tap columns 0, 4 (complement for column 2)
-    const uint32_t mB = mP ^ mbx;  // x parity of tap column 1 (complement for column 3)
-    const uint32_t mY13 = mQ ^ mby;  // y parity of tap row 1 (complement for row 3)
-
+    float C[5][3];  // per tap row: w * certainty summed per site column
 #pragma unroll
     for (int jt = 0; jt < 5; jt++) {
-        // raw row for this tap row: site row (by + jt) >> 1
-        float rr[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            if (jt == 0) rr[i] = s[0][i];
-            if (jt == 1) rr[i] = selm(mby, s[1][i], s[0][i]);
-            if (jt == 2) rr[i] = s[1][i];
-            if (jt == 3) rr[i] = selm(mby, s[2][i], s[1][i]);
-            if (jt == 4) rr[i] = s[2][i];
-        }
-        const float v[5] = {rr[0], selm(mbx, rr[1], rr[0]), rr[1], selm(mbx, rr[2], rr[1]), rr[2]};
-
-        // absolute y parity of the sites of this tap row (as a lane mask)
         uint32_t mya;
         if (jt == 0 || jt == 4) mya = mQ;
         if (jt == 2) mya = ~mQ;
         if (jt == 1) mya = mY13;
         if (jt == 3) mya = ~mY13;
-
-        // certainty texels of this tap row; cells used by pixel K: (K + it + 2) >> 2
-        constexpr int cellLo = (K + 0 + 2) >> 2, cellHi = (K + 4 + 2) >> 2;
-        float cA[2], cB[2];  // certainty for x parity 0 / 1 in the two cells
+        float Ee[2], Eo[2];  // certainty of the colour on even / odd site columns (relative to x0), per cell
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const int cell = c == 0 ? cellLo : cellHi;
             float m[3];
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) m[ch] = mval(jt, cell, ch);
-            cA[c] = selm(mya, m[Cfa<CFA>::col(1, 0)], m[Cfa<CFA>::col(0, 0)]);
-            cB[c] = selm(mya, m[Cfa<CFA>::col(1, 1)], m[Cfa<CFA>::col(0, 1)]);
+            for (int ch = 0; ch < 3; ch++) m[ch] = mval(jt, cellLo + c, ch);
+            if (mono) {
+                Ee[c] = Eo[c] = m[MFSR_GREEN];
+            } else {
+                const float cA = selm(mya, m[Cfa<CFA>::col(1, 0)], m[Cfa<CFA>::col(0, 0)]);  // absolute x parity 0
+                const float cB = selm(mya, m[Cfa<CFA>::col(1, 1)], m[Cfa<CFA>::col(0, 1)]);  // absolute x parity 1
+                Ee[c] = selm(mP, cB, cA);
+                Eo[c] = selm(mP, cA, cB);
+            }
         }
-
-        float a[5], wc[5];
-#pragma unroll
-        for (int it = 0; it < 5; it++) {
-            const int n = jt * 5 + it;
-            const float wt = w[n <= 12 ? n : 24 - n];
-            const int c = (((K + it + 2) >> 2) == cellLo) ? 0 : 1;
-            uint32_t mxa;
-            if (it == 0 || it == 4) mxa = mA;
-            if (it == 2) mxa = ~mA;
-            if (it == 1) mxa = mB;
-            if (it == 3) mxa = ~mB;
-            const float cert = selm(mxa, cB[c], cA[c]);
-            wc[it] = wt * cert;
-            a[it] = v[it] * wc[it];
+        // site column 0: tap 0, tap 1 if bx == 0
+        C[jt][0] = cidx(0) == cidx(1) ? (W_(jt, 0) + WL(jt, 1)) * Ee[cidx(0)]
+                                      : __builtin_fmaf(WL(jt, 1), Ee[cidx(1)], W_(jt, 0) * Ee[cidx(0)]);
+        // site column 1: tap 1 if bx == 1, tap 2, tap 3 if bx == 0
+        {
+            float acc;
+            if (cidx(1) == cidx(2))
+                acc = (WH(jt, 1) + W_(jt, 2)) * Eo[cidx(1)];
+            else
+                acc = __builtin_fmaf(W_(jt, 2), Eo[cidx(2)], WH(jt, 1) * Eo[cidx(1)]);
+            if (cidx(3) == cidx(1) && cidx(1) == cidx(2))
+                acc = ((WH(jt, 1) + W_(jt, 2)) + WL(jt, 3)) * Eo[cidx(1)];
+            else
+                acc = __builtin_fmaf(WL(jt, 3), Eo[cidx(3)], acc);
+            C[jt][1] = acc;
         }
-        // x classes relative to P: columns 0,4 -> 0; 2 -> 1; 1 -> bx; 3 -> !bx
-        const float rowS0 = (a[0] + a[4]) + selm(mbx, a[3], a[1]);
-        const float rowS1 = a[2] + selm(mbx, a[1], a[3]);
-        const float rowW0 = (wc[0] + wc[4]) + selm(mbx, wc[3], wc[1]);
-        const float rowW1 = wc[2] + selm(mbx, wc[1], wc[3]);
-        if (jt == 0 || jt == 4) {
-            S[0][0] += rowS0;
-            S[0][1] += rowS1;
-            W[0][0] += rowW0;
-            W[0][1] += rowW1;
-        } else if (jt == 2) {
-            S[1][0] += rowS0;
-            S[1][1] += rowS1;
-            W[1][0] += rowW0;
-            W[1][1] += rowW1;
-        } else if (jt == 1) {
-            r1S[0] = rowS0;
-            r1S[1] = rowS1;
-            r1W[0] = rowW0;
-            r1W[1] = rowW1;
-        } else {
-            r3S[0] = rowS0;
-            r3S[1] = rowS1;
-            r3W[0] = rowW0;
-            r3W[1] = rowW1;
-        }
+        // site column 2: tap 3 if bx == 1, tap 4
+        C[jt][2] = cidx(3) == cidx(4) ? (WH(jt, 3) + W_(jt, 4)) * Ee[cidx(3)]
+                                      : __builtin_fmaf(W_(jt, 4), Ee[cidx(4)], WH(jt, 3) * Ee[cidx(3)]);
     }
-    // y classes relative to Q: rows 0,4 -> 0; 2 -> 1; 1 -> by; 3 -> !by
+    // site rows: tap row 0, row 1 if by == 0 | row 1 if by == 1, row 2, row 3 if by == 0 | row 3 if by == 1, row 4
+    float Om[3][3];
 #pragma unroll
-    for (int xc = 0; xc < 2; xc++) {
-        S[0][xc] += selm(mby, r3S[xc], r1S[xc]);
-        S[1][xc] += selm(mby, r1S[xc], r3S[xc]);
-        W[0][xc] += selm(mby, r3W[xc], r1W[xc]);
-        W[1][xc] += selm(mby, r1W[xc], r3W[xc]);
+    for (int i = 0; i < 3; i++) {
+        Om[0][i] = C[0][i] + andm(nby, C[1][i]);
+        Om[1][i] = (andm(mby, C[1][i]) + C[2][i]) + andm(nby, C[3][i]);
+        Om[2][i] = andm(mby, C[3][i]) + C[4][i];
     }
+    // class (yc, xc) = (j & 1, i & 1), relative to (Q, P)
+    float S[2][2], W[2][2];
+    S[0][0] = __builtin_fmaf(s[2][2], Om[2][2], __builtin_fmaf(s[2][0], Om[2][0], __builtin_fmaf(s[0][2], Om[0][2], s[0][0] * Om[0][0])));
+    W[0][0] = (Om[0][0] + Om[0][2]) + (Om[2][0] + Om[2][2]);
+    S[0][1] = __builtin_fmaf(s[2][1], Om[2][1], s[0][1] * Om[0][1]);
+    W[0][1] = Om[0][1] + Om[2][1];
+    S[1][0] = __builtin_fmaf(s[1][2], Om[1][2], s[1][0] * Om[1][0]);
+    W[1][0] = Om[1][0] + Om[1][2];
+    S[1][1] = s[1][1] * Om[1][1];
+    W[1][1] = Om[1][1];
 
-    // relative class (yc, xc) sits at CFA position (yc ^ Q, xc ^ P)
     auto at_pos = [&](const float(&T)[2][2], int yp, int xp) {
         const float q0 = selm(mP, T[yp][xp ^ 1], T[yp][xp]);          // Q == 0
         const float q1 = selm(mP, T[yp ^ 1][xp ^ 1], T[yp ^ 1][xp]);  // Q == 1
         return selm(mQ, q1, q0);
     };
     float chS[3] = {0, 0, 0}, chW[3] = {0, 0, 0};
-    constexpr int nG = Cfa<CFA>::count(MFSR_GREEN);
-    if (nG == 4) {  // monochrome
-        chS[1] = (S[0][0] + S[0][1]) + (S[1][0] + S[1][1]);
-        chW[1] = (W[0][0] + W[0][1]) + (W[1][0] + W[1][1]);
-    } else {  // Bayer: one red, one blue, two greens
-        // weights are in [0,1] on this path (PSD kernel parameters), so the two green positions
-        // can be taken as total - red - blue without cancellation trouble
+    const float totS = (S[0][0] + S[0][1]) + (S[1][0] + S[1][1]);
+    const float totW = (W[0][0] + W[0][1]) + (W[1][0] + W[1][1]);
+    if (mono) {
+        chS[1] = totS;
+        chW[1] = totW;
+    } else {
         constexpr int pr = Cfa<CFA>::pos_of(MFSR_RED), pb = Cfa<CFA>::pos_of(MFSR_BLUE);
-        const float totS = (S[0][0] + S[0][1]) + (S[1][0] + S[1][1]);
-        const float totW = (W[0][0] + W[0][1]) + (W[1][0] + W[1][1]);
         chS[0] = at_pos(S, pr >> 1, pr & 1);
         chW[0] = at_pos(W, pr >> 1, pr & 1);
         chS[2] = at_pos(S, pb >> 1, pb & 1);
@@ -433,337 +427,31 @@ __global__ void __launch_bounds__(256)
     pW[2] = make_float4(accW[8], accW[9], accW[10], accW[11]);
 }
 
-// ---- uniform-shift strips -----------------------------------------------------------------
-// The flow is smooth, so nearly every strip has ONE rounded shift (sx, sy) for its four pixels.
-// Then the strip is a rigid 4x1 block in the raw frame and everything that strip_pixel resolves
-// per lane and per tap with selects is a compile-time function of two bits, SIG = sx & 1 and
-// BY = (Y + sy) & 1 (the kernel dispatches on them; in a wave whose strips agree only one of the
-// four bodies runs):
-//  * the four pixels share 3 x (4 + SIG) raw sites: 12..15 loads per strip instead of 36;
-//  * which site a tap hits, which certainty cell it reads and which CFA-position class it adds
-//    to are static, so the per-tap work is one multiply, one fma and one add;
-//  * the certainty of (site colour, cell) is resolved once per strip and tap row (E[][]) with
-//    the two per-lane CFA phase masks, instead of per pixel and per tap;
-//  * taps of a pixel that land on the same site and read the same cell add their weights first;
-//  * the 12 non-trivial exponents are built from pre-scaled sums (2 adds each, no multiply).
-// The sums are re-associated once more against strip_pixel (and use fma), so results agree to
-// ~1e-6 relative, as between strip_pixel and the straight kernel.
-template <int SIG>
-struct UGeom {
-    static constexpr int NCOL = SIG ? 5 : 4;  // raw site columns the strip touches
-    static constexpr int NE = SIG ? 7 : 4;    // distinct (site column, certainty cell) pairs per tap row
-    // m = K + it (0..7): HR tap column relative to X0 - 2
-    static constexpr int site(int m) { return (m + SIG) >> 1; }
-    static constexpr int cell(int m) { return (m + 2) >> 2; }  // 0..2 <-> mask column tx-1 .. tx+1
-    static constexpr int eid(int m)
-    {
-        if (!SIG) return m >> 1;
-        constexpr int t[8] = {0, 1, 2, 3, 3, 4, 5, 6};
-        return t[m];
-    }
-    static constexpr int rep(int e)  // a representative m of pair e
-    {
-        for (int m = 0; m < 8; m++)
-            if (eid(m) == e) return m;
-        return 0;
-    }
-};
-
-template <int CFA, int SIG, int BY, typename MRowF>
-__device__ __forceinline__ void strip_uniform(int X0, int Y, int sx, int sy, const float (&kxa)[4], const float (&kya)[4],
-                                              const float (&kza)[4], const uint16_t* __restrict__ raw, int dimX,
-                                              MRowF mrow, const StripLevels& lv, float* accP, float* accW)
-{
-    using G = UGeom<SIG>;
-    const int qx0 = X0 + sx - 2, qy = Y + sy - 2;  // qx0 & 1 == SIG, qy & 1 == BY
-    const int xb = qx0 >> 1, y0 = qy >> 1;
-    const uint32_t mP = 0u - (uint32_t)(xb & 1), mQ = 0u - (uint32_t)(y0 & 1);
-    constexpr bool mono = Cfa<CFA>::count(MFSR_GREEN) == 4;
-
-    float s[3][G::NCOL];
-    {
-        const uint16_t* r = raw + (size_t)y0 * dimX + xb;
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-#pragma unroll
-            for (int c = 0; c < G::NCOL; c++) s[j][c] = (float)r[j * dimX + c];
-    }
-
-    // certainty of the colour at site (row of tap row jt, column site(m)) in cell(m)
-    float E[5][G::NE];
-#pragma unroll
-    for (int jt = 0; jt < 5; jt++) {
-        const int yc = ((BY + jt) >> 1) & 1;  // site row parity relative to Q
-        float c0[3], c1[3];                   // per cell: certainty at absolute x parity 0 / 1 on this site row
-#pragma unroll
-        for (int cl = 0; cl < 3; cl++) {
-            bool used = false;
-#pragma unroll
-            for (int m = 0; m < 8; m++) used = used || G::cell(m) == cl;
-            if (!used) continue;
-            const float4 q = mrow(jt, cl);
-            const float mm[3] = {q.x, q.y, q.z};
-            if (mono) {
-                c0[cl] = c1[cl] = mm[MFSR_GREEN];
-            } else if (yc == 0) {
-                c0[cl] = selm(mQ, mm[Cfa<CFA>::col(1, 0)], mm[Cfa<CFA>::col(0, 0)]);
-                c1[cl] = selm(mQ, mm[Cfa<CFA>::col(1, 1)], mm[Cfa<CFA>::col(0, 1)]);
-            } else {
-                c0[cl] = selm(mQ, mm[Cfa<CFA>::col(0, 0)], mm[Cfa<CFA>::col(1, 0)]);
-                c1[cl] = selm(mQ, mm[Cfa<CFA>::col(0, 1)], mm[Cfa<CFA>::col(1, 1)]);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < G::NE; e++) {
-            const int m = G::rep(e), cl = G::cell(m), xc = G::site(m) & 1;
-            if (mono)
-                E[jt][e] = c0[cl];
-            else
-                E[jt][e] = xc == 0 ? selm(mP, c1[cl], c0[cl]) : selm(mP, c0[cl], c1[cl]);
-        }
-    }
-
-#pragma unroll
-    for (int K = 0; K < 4; K++) {
-        const int oK = (K + SIG) >> 1, bx = (K + SIG) & 1;
-        // 13 unique weights, n = jt*5+it, w[n] == w[24-n]; exponent pre-scaled by -0.5*log2(e)
-        float w[13];
-        {
-            const float a1 = kxa[K] * -0.72134752044448170368f, b1 = kya[K] * -0.72134752044448170368f;
-            const float c1 = kza[K] * -0.72134752044448170368f;
-            const float a4 = 4.0f * a1, b4 = 4.0f * b1;
-            const float A[3] = {0.0f, a1, a4}, B[3] = {0.0f, b1, b4};
-            float D[3][3];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) D[i][j] = (i == 0) ? B[j] : (j == 0 ? A[i] : A[i] + B[j]);
-#pragma unroll
-            for (int n = 0; n < 13; n++) {
-                const int py = n / 5 - 2, px = n % 5 - 2;
-                const int apx = px < 0 ? -px : px, apy = py < 0 ? -py : py;
-                if (n == 12) {
-                    w[n] = 1.0f;
-                } else if (px * py == 0) {
-                    w[n] = __builtin_amdgcn_exp2f(D[apx][apy]);
-                } else {
-                    w[n] = __builtin_amdgcn_exp2f(D[apx][apy] + (float)(2 * px * py) * c1);
-                }
-            }
-        }
-        float S[2][2] = {{0, 0}, {0, 0}}, W[2][2] = {{0, 0}, {0, 0}};
-#pragma unroll
-        for (int jt = 0; jt < 5; jt++) {
-            const int j = (BY + jt) >> 1, yc = j & 1;
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                // taps of this tap row that land on site column oK + i
-                int ita = -1, itb = -1;
-#pragma unroll
-                for (int it = 0; it < 5; it++)
-                    if (((bx + it) >> 1) == i) {
-                        if (ita < 0)
-                            ita = it;
-                        else
-                            itb = it;
-                    }
-                const int c = oK + i, xc = c & 1;
-                const int na = jt * 5 + ita;
-                const float wa = w[na <= 12 ? na : 24 - na];
-                float wc;
-                if (itb < 0) {
-                    wc = wa * E[jt][G::eid(K + ita)];
-                } else {
-                    const int nb = jt * 5 + itb;
-                    const float wb = w[nb <= 12 ? nb : 24 - nb];
-                    if (G::eid(K + ita) == G::eid(K + itb))
-                        wc = (wa + wb) * E[jt][G::eid(K + ita)];
-                    else
-                        wc = __builtin_fmaf(wb, E[jt][G::eid(K + itb)], wa * E[jt][G::eid(K + ita)]);
-                }
-                S[yc][xc] = __builtin_fmaf(s[j][c], wc, S[yc][xc]);
-                W[yc][xc] += wc;
-            }
-        }
-        // relative class (yc, xc) sits at CFA position (yc ^ Q, xc ^ P)
-        auto at_pos = [&](const float(&T)[2][2], int yp, int xp) {
-            const float q0 = selm(mP, T[yp][xp ^ 1], T[yp][xp]);          // Q == 0
-            const float q1 = selm(mP, T[yp ^ 1][xp ^ 1], T[yp ^ 1][xp]);  // Q == 1
-            return selm(mQ, q1, q0);
-        };
-        float chS[3] = {0, 0, 0}, chW[3] = {0, 0, 0};
-        const float totS = (S[0][0] + S[0][1]) + (S[1][0] + S[1][1]);
-        const float totW = (W[0][0] + W[0][1]) + (W[1][0] + W[1][1]);
-        if (mono) {
-            chS[1] = totS;
-            chW[1] = totW;
-        } else {
-            constexpr int pr = Cfa<CFA>::pos_of(MFSR_RED), pb = Cfa<CFA>::pos_of(MFSR_BLUE);
-            chS[0] = at_pos(S, pr >> 1, pr & 1);
-            chW[0] = at_pos(W, pr >> 1, pr & 1);
-            chS[2] = at_pos(S, pb >> 1, pb & 1);
-            chW[2] = at_pos(W, pb >> 1, pb & 1);
-            chS[1] = (totS - chS[0]) - chS[2];
-            chW[1] = (totW - chW[0]) - chW[2];
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            accP[3 * K + c] += (chS[c] - lv.black[c] * chW[c]) * lv.invWhite[c];
-            accW[3 * K + c] += chW[c];
-        }
-    }
-}
-
-// ---- LDS-tiled variant (fields at HR/4: the Bayer pipeline) ------------------------------
-// One 64x4 workgroup covers a 256 x 4 HR tile.  The kernel-parameter / flow texels and the
-// certainty texels that the tile touches (3 rows x 66 columns each) are staged once in LDS
-// (certainties sanitised while staging), so a thread keeps neither field texels nor
-// certainty texels in registers across its four pixels: fewer global loads (6.2 KB per
-// workgroup instead of ~46 KB) and a smaller register footprint (more waves per SIMD).
+// ---- LDS tile kernel (fields at HR/4: the Bayer pipeline) --------------------------------------
+// One 64x4 workgroup covers a 256 x 4 HR tile.
+//  * The kernel-parameter / flow / certainty texels the tile touches (3 rows x 66 columns each) are
+//    staged once in LDS (certainties sanitised, kernel parameters tagged "positive semi-definite"
+//    while staging), and so are the per-column and per-row interpolation fractions (one IEEE
+//    division per column of the tile instead of one per pixel).
+//  * The two accumulator row segments of a wave (3 KiB each) go global -> LDS with
+//    global_load_lds (no VGPRs, 1 KiB contiguous per instruction, in flight during the whole tap
+//    arithmetic), are updated in LDS and written back in memory order: every accumulator access
+//    on the HBM side is a fully used 128-byte line.
 #define TILE_COLS 66
 #ifndef TILE_WAVES
 #define TILE_WAVES 4
 #endif
-template <int CFA, bool UNI>
+template <int CFA>
 __global__ void __launch_bounds__(256, TILE_WAVES)
     k_accumulate2xTile(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
                        const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
                        StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
 {
-    __shared__ float4 sK[3][TILE_COLS];
+    __shared__ float4 sK[3][TILE_COLS];  // .w = 1 if the texel is PSD and finite, else 0
     __shared__ float2 sF[3][TILE_COLS];
     __shared__ float4 sM[3][TILE_COLS];
-    const int lx = threadIdx.x, ly = threadIdx.y;
-    const int tx = blockIdx.x * 64 + lx;
-    const int Y = blockIdx.y * 4 + ly;
-    const int hrW = 2 * dimX, hrH = 2 * dimY;
-    const int X0 = 4 * tx;
-    const int fw = kernelParam.width, fh = kernelParam.height;  // == hrW/4, hrH/4 (checked on the host)
-    const int mw = dimX / 2, mh = dimY / 2;                       // certainty mask size
-    {
-        const int t = ly * 64 + lx;
-        if (t < 3 * TILE_COLS) {
-            const int r = t / TILE_COLS, c = t - r * TILE_COLS;
-            const int gy = (int)blockIdx.y - 1 + r, gx = (int)blockIdx.x * 64 - 1 + c;
-            const int fy = clampi(gy, 0, fh - 1), fx = clampi(gx, 0, fw - 1);
-            sK[r][c] = row_ptr((const float4*)kernelParam.ptr, kernelParam.pitch, fy)[fx];
-            sF[r][c] = row_ptr((const float2*)shifts.ptr, shifts.pitch, fy)[fx];
-            const float4 m = row_ptr(certaintyMask, strideMask, clampi(gy, 0, mh - 1))[clampi(gx, 0, mw - 1)];
-            sM[r][c] = make_float4(sane(m.x), sane(m.y), sane(m.z), 0.0f);
-        }
-    }
-    __syncthreads();
-    if (X0 < STRIP_MARGIN || X0 >= hrW - STRIP_MARGIN || Y < STRIP_MARGIN || Y >= hrH - STRIP_MARGIN) return;
-
-    // field row: the same float path as tex_coord; LDS row predicted from ly and verified
-    const float posY = ((float)Y + 0.5f) / (float)hrH;
-    float yB = posY * (float)fh - 0.5f;
-    if (!finitef(yB)) yB = 0.0f;
-    const float fyf = floorf(yB);
-    const float b = yB - fyf;
-    const int fr = ly < 2 ? 0 : 1;  // LDS row of texel row j0 = floor(yB)
-    bool safe = true;  // (the frame margin is handled by k_accumulateMargin)
-    safe = safe && (f2i(fyf) == (int)blockIdx.y - 1 + fr) && f2i(fyf) >= 0 && f2i(fyf) + 1 <= fh - 1;
-
-    int sx[4], sy[4];
-    float av[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float posX = ((float)(X0 + k) + 0.5f) / (float)hrW;
-        float xB = posX * (float)fw - 0.5f;
-        if (!finitef(xB)) xB = 0.0f;
-        const float fxf = floorf(xB);
-        av[k] = xB - fxf;
-        const int ci = k < 2 ? 0 : 1;
-        safe = safe && (f2i(fxf) == tx - 1 + ci) && (tx + ci <= fw - 1);
-        const float2 t00 = sF[fr][lx + ci], t10 = sF[fr][lx + ci + 1], t01 = sF[fr + 1][lx + ci], t11 = sF[fr + 1][lx + ci + 1];
-        const float ux = lerp4(t00.x, t10.x, t01.x, t11.x, av[k], b);
-        const float uy = lerp4(t00.y, t10.y, t01.y, t11.y, av[k], b);
-        sx[k] = f2i(roundf(ux * 2.0f));
-        sy[k] = f2i(roundf(uy * 2.0f));
-        const int qx = X0 + k + sx[k] - 2, qy = Y + sy[k] - 2;
-        safe = safe && qx >= 0 && ((qx + 4) >> 1) <= dimX - 1 && qy >= 0 && ((qy + 4) >> 1) <= dimY - 1;
-        safe = safe && sx[k] > -(1 << 20) && sx[k] < (1 << 20) && sy[k] > -(1 << 20) && sy[k] < (1 << 20);
-    }
-    auto kfetch = [&](int k, float& kx, float& ky, float& kz) {
-        const int ci = k < 2 ? 0 : 1;
-        const float4 t00 = sK[fr][lx + ci], t10 = sK[fr][lx + ci + 1], t01 = sK[fr + 1][lx + ci], t11 = sK[fr + 1][lx + ci + 1];
-        kx = lerp4(t00.x, t10.x, t01.x, t11.x, av[k], b);
-        ky = lerp4(t00.y, t10.y, t01.y, t11.y, av[k], b);
-        kz = lerp4(t00.z, t10.z, t01.z, t11.z, av[k], b);
-    };
-    float kxa[4], kya[4], kza[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        kfetch(k, kxa[k], kya[k], kza[k]);
-        safe = safe && psd_ok(kxa[k], kya[k], kza[k]);
-    }
-    if (!safe) {
-#pragma unroll 1
-        for (int k = 0; k < 4; k++) {
-            const int X = X0 + k;
-            if (X >= 1 && X < hrW - 1)
-                accumulate_pixel_generic<GEOM_FULL, true>(X, Y, raw, imgOut, totalWeights, certaintyMask, kernelParam,
-                                                          shifts, glv, dimX, dimY, 2, strideOut, strideMask, cfaPacked);
-        }
-        return;
-    }
-
-    float4* pP = (float4*)((char*)imgOut + (size_t)Y * strideOut + (size_t)X0 * 12);
-    float4* pW = (float4*)((char*)totalWeights + (size_t)Y * strideOut + (size_t)X0 * 12);
-    float accP[12], accW[12];
-    {
-        const float4 a0 = pP[0], a1 = pP[1], a2 = pP[2];
-        const float4 b0 = pW[0], b1 = pW[1], b2 = pW[2];
-        accP[0] = a0.x; accP[1] = a0.y; accP[2] = a0.z; accP[3] = a0.w;
-        accP[4] = a1.x; accP[5] = a1.y; accP[6] = a1.z; accP[7] = a1.w;
-        accP[8] = a2.x; accP[9] = a2.y; accP[10] = a2.z; accP[11] = a2.w;
-        accW[0] = b0.x; accW[1] = b0.y; accW[2] = b0.z; accW[3] = b0.w;
-        accW[4] = b1.x; accW[5] = b1.y; accW[6] = b1.z; accW[7] = b1.w;
-        accW[8] = b2.x; accW[9] = b2.y; accW[10] = b2.z; accW[11] = b2.w;
-    }
-
-    // certainty: LDS row of the mask row that tap row jt reads = ((ly + jt - 2) >> 2) + 1; column lx + cell
-    auto mval = [&](int jt, int cell, int ch) {
-        const int mr = ((ly + jt - 2) >> 2) + 1;
-        const float* p = (const float*)&sM[mr][lx + cell];
-        return p[ch];
-    };
-    auto mrow = [&](int jt, int cell) { return sM[((ly + jt - 2) >> 2) + 1][lx + cell]; };
-    const bool uni = UNI && sx[1] == sx[0] && sx[2] == sx[0] && sx[3] == sx[0] && sy[1] == sy[0] && sy[2] == sy[0] &&
-                     sy[3] == sy[0];
-    if (uni) {
-        switch ((sx[0] & 1) | (((Y + sy[0]) & 1) << 1)) {
-            case 0: strip_uniform<CFA, 0, 0>(X0, Y, sx[0], sy[0], kxa, kya, kza, raw, dimX, mrow, lv, accP, accW); break;
-            case 1: strip_uniform<CFA, 1, 0>(X0, Y, sx[0], sy[0], kxa, kya, kza, raw, dimX, mrow, lv, accP, accW); break;
-            case 2: strip_uniform<CFA, 0, 1>(X0, Y, sx[0], sy[0], kxa, kya, kza, raw, dimX, mrow, lv, accP, accW); break;
-            default: strip_uniform<CFA, 1, 1>(X0, Y, sx[0], sy[0], kxa, kya, kza, raw, dimX, mrow, lv, accP, accW); break;
-        }
-    } else {
-        strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
-        strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
-        strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
-        strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
-    }
-
-    pP[0] = make_float4(accP[0], accP[1], accP[2], accP[3]);
-    pP[1] = make_float4(accP[4], accP[5], accP[6], accP[7]);
-    pP[2] = make_float4(accP[8], accP[9], accP[10], accP[11]);
-    pW[0] = make_float4(accW[0], accW[1], accW[2], accW[3]);
-    pW[1] = make_float4(accW[4], accW[5], accW[6], accW[7]);
-    pW[2] = make_float4(accW[8], accW[9], accW[10], accW[11]);
-}
-
-// ---- LDS tile + accumulator segments staged by LDS-DMA ---------------------------------
-template <int CFA>
-__global__ void __launch_bounds__(256, TILE_WAVES)
-    k_accumulate2xTileDma(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
-                       const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
-                       StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
-{
-    __shared__ float4 sK[3][TILE_COLS];
-    __shared__ float2 sF[3][TILE_COLS];
-    __shared__ float4 sM[3][TILE_COLS];
+    __shared__ __attribute__((aligned(16))) float sColA[256];  // x fraction per HR column of the tile, -1 = not on the predicted texel
+    __shared__ float sRowB[4];                                 // y fraction per HR row of the tile, -1 likewise
     // accumulator staging: per wave and plane-set the wave's 3 KiB row segment, in memory order
     __shared__ __attribute__((aligned(16))) float4 sAcc[4][2][192];
     const int lx = threadIdx.x, ly = threadIdx.y;
@@ -779,14 +467,37 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
             const int r = t / TILE_COLS, c = t - r * TILE_COLS;
             const int gy = (int)blockIdx.y - 1 + r, gx = (int)blockIdx.x * 64 - 1 + c;
             const int fy = clampi(gy, 0, fh - 1), fx = clampi(gx, 0, fw - 1);
-            sK[r][c] = row_ptr((const float4*)kernelParam.ptr, kernelParam.pitch, fy)[fx];
+            float4 k = row_ptr((const float4*)kernelParam.ptr, kernelParam.pitch, fy)[fx];
+            // a bilinear mix of PSD matrices is PSD, so admitting texels admits every pixel between them
+            k.w = psd_ok(k.x, k.y, k.z) ? 1.0f : 0.0f;
+            sK[r][c] = k;
             sF[r][c] = row_ptr((const float2*)shifts.ptr, shifts.pitch, fy)[fx];
             const float4 m = row_ptr(certaintyMask, strideMask, clampi(gy, 0, mh - 1))[clampi(gx, 0, mw - 1)];
             sM[r][c] = make_float4(sane(m.x), sane(m.y), sane(m.z), 0.0f);
         }
+        {
+            // column t of the tile: the float path of tex_coord, texel column predicted and verified
+            const int X = (int)blockIdx.x * 256 + t;
+            const float posX = ((float)X + 0.5f) / (float)hrW;
+            float xB = posX * (float)fw - 0.5f;
+            if (!finitef(xB)) xB = 0.0f;
+            const float fxf = floorf(xB);
+            const int txc = X >> 2, ci = (t & 3) < 2 ? 0 : 1;
+            const bool ok = (f2i(fxf) == txc - 1 + ci) && (txc + ci <= fw - 1);
+            sColA[t] = ok ? xB - fxf : -1.0f;
+        }
+        if (t < 4) {
+            const int Yr = (int)blockIdx.y * 4 + t;
+            const float posY = ((float)Yr + 0.5f) / (float)hrH;
+            float yB = posY * (float)fh - 0.5f;
+            if (!finitef(yB)) yB = 0.0f;
+            const float fyf = floorf(yB);
+            const int frr = t < 2 ? 0 : 1;  // LDS row of texel row floor(yB)
+            const bool ok = (f2i(fyf) == (int)blockIdx.y - 1 + frr) && f2i(fyf) >= 0 && f2i(fyf) + 1 <= fh - 1;
+            sRowB[t] = ok ? yB - fyf : -1.0f;
+        }
     }
-    // asynchronous global -> LDS copy of both accumulator segments (no VGPRs, contiguous 1 KiB per
-    // instruction); consumed only after the tap arithmetic
+    // asynchronous global -> LDS copy of both accumulator segments; consumed only after the tap arithmetic
     const bool rowLive = Y >= STRIP_MARGIN && Y < hrH - STRIP_MARGIN;
     const size_t rowBytes = (size_t)hrW * 12;
     const size_t segByte = (size_t)blockIdx.x * 3072;
@@ -808,48 +519,42 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
     if (!rowLive) return;
     const bool stripLive = X0 >= STRIP_MARGIN && X0 < hrW - STRIP_MARGIN;
 
-    // field row: the same float path as tex_coord; LDS row predicted from ly and verified
-    const float posY = ((float)Y + 0.5f) / (float)hrH;
-    float yB = posY * (float)fh - 0.5f;
-    if (!finitef(yB)) yB = 0.0f;
-    const float fyf = floorf(yB);
-    const float b = yB - fyf;
-    const int fr = ly < 2 ? 0 : 1;  // LDS row of texel row j0 = floor(yB)
-    bool safe = stripLive;  // (the frame margin is handled by k_accumulateMargin)
-    safe = safe && (f2i(fyf) == (int)blockIdx.y - 1 + fr) && f2i(fyf) >= 0 && f2i(fyf) + 1 <= fh - 1;
+    const int fr = ly < 2 ? 0 : 1;
+    const float b = sRowB[ly];
+    const float4 av4 = ((const float4*)sColA)[lx];
+    const float av[4] = {av4.x, av4.y, av4.z, av4.w};
+    bool safe = stripLive && b >= 0.0f && fminf(fminf(av[0], av[1]), fminf(av[2], av[3])) >= 0.0f;
+
+    // texels of this strip: 3 columns x 2 rows
+    float4 Kt[2][3];
+    float2 Ft[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            Kt[r][c] = sK[fr + r][lx + c];
+            Ft[r][c] = sF[fr + r][lx + c];
+        }
+    safe = safe && (((Kt[0][0].w * Kt[0][1].w) * (Kt[0][2].w * Kt[1][0].w)) * (Kt[1][1].w * Kt[1][2].w) > 0.0f);
 
     int sx[4], sy[4];
-    float av[4];
+    float kxa[4], kya[4], kza[4];
+    const uint32_t xmax = (uint32_t)(2 * dimX - 5), ymax = (uint32_t)(2 * dimY - 5);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const float posX = ((float)(X0 + k) + 0.5f) / (float)hrW;
-        float xB = posX * (float)fw - 0.5f;
-        if (!finitef(xB)) xB = 0.0f;
-        const float fxf = floorf(xB);
-        av[k] = xB - fxf;
         const int ci = k < 2 ? 0 : 1;
-        safe = safe && (f2i(fxf) == tx - 1 + ci) && (tx + ci <= fw - 1);
-        const float2 t00 = sF[fr][lx + ci], t10 = sF[fr][lx + ci + 1], t01 = sF[fr + 1][lx + ci], t11 = sF[fr + 1][lx + ci + 1];
-        const float ux = lerp4(t00.x, t10.x, t01.x, t11.x, av[k], b);
-        const float uy = lerp4(t00.y, t10.y, t01.y, t11.y, av[k], b);
+        const float ux = lerp4(Ft[0][ci].x, Ft[0][ci + 1].x, Ft[1][ci].x, Ft[1][ci + 1].x, av[k], b);
+        const float uy = lerp4(Ft[0][ci].y, Ft[0][ci + 1].y, Ft[1][ci].y, Ft[1][ci + 1].y, av[k], b);
         sx[k] = f2i(roundf(ux * 2.0f));
         sy[k] = f2i(roundf(uy * 2.0f));
+        // every tap inside the frame: 0 <= q and ((q + 4) >> 1) <= dim - 1  <=>  (unsigned)q <= 2*dim - 5;
+        // the range test on the rounded flow keeps saturated conversions from wrapping back into range
         const int qx = X0 + k + sx[k] - 2, qy = Y + sy[k] - 2;
-        safe = safe && qx >= 0 && ((qx + 4) >> 1) <= dimX - 1 && qy >= 0 && ((qy + 4) >> 1) <= dimY - 1;
-        safe = safe && sx[k] > -(1 << 20) && sx[k] < (1 << 20) && sy[k] > -(1 << 20) && sy[k] < (1 << 20);
-    }
-    auto kfetch = [&](int k, float& kx, float& ky, float& kz) {
-        const int ci = k < 2 ? 0 : 1;
-        const float4 t00 = sK[fr][lx + ci], t10 = sK[fr][lx + ci + 1], t01 = sK[fr + 1][lx + ci], t11 = sK[fr + 1][lx + ci + 1];
-        kx = lerp4(t00.x, t10.x, t01.x, t11.x, av[k], b);
-        ky = lerp4(t00.y, t10.y, t01.y, t11.y, av[k], b);
-        kz = lerp4(t00.z, t10.z, t01.z, t11.z, av[k], b);
-    };
-    float kxa[4], kya[4], kza[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        kfetch(k, kxa[k], kya[k], kza[k]);
-        safe = safe && psd_ok(kxa[k], kya[k], kza[k]);
+        safe = safe && (uint32_t)(sx[k] + (1 << 20)) < (2u << 20) && (uint32_t)(sy[k] + (1 << 20)) < (2u << 20) &&
+               (uint32_t)qx <= xmax && (uint32_t)qy <= ymax;
+        kxa[k] = lerp4(Kt[0][ci].x, Kt[0][ci + 1].x, Kt[1][ci].x, Kt[1][ci + 1].x, av[k], b);
+        kya[k] = lerp4(Kt[0][ci].y, Kt[0][ci + 1].y, Kt[1][ci].y, Kt[1][ci + 1].y, av[k], b);
+        kza[k] = lerp4(Kt[0][ci].z, Kt[0][ci + 1].z, Kt[1][ci].z, Kt[1][ci + 1].z, av[k], b);
     }
     float accP[12], accW[12];
 #pragma unroll
@@ -857,17 +562,16 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
     float* myP = (float*)&sAcc[ly][0][0] + lx * 12;  // this lane's 4 pixels x 3 channels inside the staged segment
     float* myW = (float*)&sAcc[ly][1][0] + lx * 12;
     if (safe) {
-    // certainty: LDS row of the mask row that tap row jt reads = ((ly + jt - 2) >> 2) + 1; column lx + cell
-    auto mval = [&](int jt, int cell, int ch) {
-        const int mr = ((ly + jt - 2) >> 2) + 1;
-        const float* p = (const float*)&sM[mr][lx + cell];
-        return p[ch];
-    };
-    strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
-    strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
-    strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
-    strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
-
+        // certainty: LDS row of the mask row that tap row jt reads = ((ly + jt - 2) >> 2) + 1; column lx + cell
+        auto mval = [&](int jt, int cell, int ch) {
+            const int mr = ((ly + jt - 2) >> 2) + 1;
+            const float* p = (const float*)&sM[mr][lx + cell];
+            return p[ch];
+        };
+        strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
+        strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
+        strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
+        strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
     }
     // staged accumulators must have landed before anyone reads them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -881,7 +585,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
             ((float4*)myW)[j] = c;
         }
     } else if (stripLive) {
-        // border / wild-flow strips: the straight per-pixel arithmetic on the staged values
+        // border / wild-flow / non-PSD strips: the straight per-pixel arithmetic on the staged values
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
             const int X = X0 + k;
@@ -909,7 +613,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
 
 constexpr int pack_cfa(int c00, int c01, int c10, int c11) { return c00 | (c01 << 2) | (c10 << 4) | (c11 << 6); }
 
-int g_strip_use_tile = 1;  // MFSR_STRIP_TILE: 0 register-only strip kernel, 1 LDS tile, 2 LDS tile + LDS-DMA accumulators
+int g_strip_use_tile = 1;  // MFSR_STRIP_TILE: 0 register-only strip kernel, 1 LDS tile kernel (fields at HR/4)
 
 template <int CFA>
 void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pix3* imgOut, pix3* tw, const float4* mask,
@@ -919,16 +623,8 @@ void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pi
     const int hrW = 2 * dimX, hrH = 2 * dimY;
     const bool same = kp.width == sh.width && kp.height == sh.height;
     if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4 && (dimX % 4) == 0 && (dimY % 4) == 0 &&
-        g_strip_use_tile == 2)
-        hipLaunchKernelGGL((k_accumulate2xTileDma<CFA>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
-                           dimY, strideOut, strideMask, cfaPacked);
-    else if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4 && (dimX % 4) == 0 && (dimY % 4) == 0 &&
-             g_strip_use_tile == 3)
-        hipLaunchKernelGGL((k_accumulate2xTile<CFA, true>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX, dimY,
-                           strideOut, strideMask, cfaPacked);
-    else if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4 && (dimX % 4) == 0 && (dimY % 4) == 0 &&
-             g_strip_use_tile == 1)
-        hipLaunchKernelGGL((k_accumulate2xTile<CFA, false>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX, dimY,
+        g_strip_use_tile == 1)
+        hipLaunchKernelGGL((k_accumulate2xTile<CFA>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX, dimY,
                            strideOut, strideMask, cfaPacked);
     else if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4)
         hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 4>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
@@ -952,7 +648,7 @@ int mfsr_try_launch_accumulate2x_strip(const uint16_t* dataIn, mfsr_float3* imgO
 {
     static const bool env_read = [] {
         const char* e = getenv("MFSR_STRIP_TILE");
-        if (e && e[0] >= '0' && e[0] <= '3') g_strip_use_tile = e[0] - '0';
+        if (e && e[0] >= '0' && e[0] <= '1') g_strip_use_tile = e[0] - '0';
         return true;
     }();
     (void)env_read;
