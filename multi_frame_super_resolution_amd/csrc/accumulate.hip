@@ -33,8 +33,8 @@ __global__ void __launch_bounds__(256)
     pix3 totalWeight = row_ptr(totalWeights, strideOut, y)[x];
     const pix3 kernel = row_ptr(kernelParam, strideOut, y)[x];  // strideOut: reference quirk (:308)
     const float2 shift = row_ptr(shifts, strideShift, y)[x];
-    const int sx = f2i(roundf(shift.x));
-    const int sy = f2i(roundf(shift.y));
+    const int sx = round2i(shift.x);
+    const int sy = round2i(shift.y);
 #pragma unroll
     for (int py = -2; py <= 2; py++) {
         const int ppsy = clampi(y + py + sy, 0, dimY - 1);

@@ -98,8 +98,8 @@ __device__ __forceinline__ void accumulate_pixel_core(int x, int y, const uint16
     }
     const float4 kernel = tex4<ADDR_CLAMP>(kernelParam, posX, posY);
     const float2 shift = tex2<ADDR_CLAMP>(shifts, posX, posY);
-    const int sx = f2i(roundf(shift.x * fscale));  // :403-406
-    const int sy = f2i(roundf(shift.y * fscale));
+    const int sx = round2i(shift.x * fscale);  // :403-406
+    const int sy = round2i(shift.y * fscale);
 
     int ppsxA[5], ppxA[5];
 #pragma unroll

@@ -170,6 +170,19 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
             for (int ch = 0; ch < 3; ch++) m[ch] = mval(jt, cellLo + c, ch);
             if (mono) {
                 Ee[c] = Eo[c] = m[MFSR_GREEN];
+            } else if (Cfa<CFA>::col(0, 1) == Cfa<CFA>::col(1, 0)) {
+                // Bayer, G on the anti-diagonal (RGGB, BGGR): the colour on the diagonal is picked by the y
+                // parity alone; even site columns see it when x parity == y parity, else they see G
+                const float X = selm(mya, m[Cfa<CFA>::col(1, 1)], m[Cfa<CFA>::col(0, 0)]);
+                const uint32_t d = mya ^ mP;  // x parity != y parity
+                Ee[c] = selm(d, m[Cfa<CFA>::col(0, 1)], X);
+                Eo[c] = selm(d, X, m[Cfa<CFA>::col(0, 1)]);
+            } else if (Cfa<CFA>::col(0, 0) == Cfa<CFA>::col(1, 1)) {
+                // Bayer, G on the diagonal (GRBG, GBRG)
+                const float X = selm(mya, m[Cfa<CFA>::col(1, 0)], m[Cfa<CFA>::col(0, 1)]);
+                const uint32_t d = mya ^ mP;
+                Ee[c] = selm(d, X, m[Cfa<CFA>::col(0, 0)]);
+                Eo[c] = selm(d, m[Cfa<CFA>::col(0, 0)], X);
             } else {
                 const float cA = selm(mya, m[Cfa<CFA>::col(1, 0)], m[Cfa<CFA>::col(0, 0)]);  // absolute x parity 0
                 const float cB = selm(mya, m[Cfa<CFA>::col(1, 1)], m[Cfa<CFA>::col(0, 1)]);  // absolute x parity 1
@@ -229,10 +242,23 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
         chW[1] = totW;
     } else {
         constexpr int pr = Cfa<CFA>::pos_of(MFSR_RED), pb = Cfa<CFA>::pos_of(MFSR_BLUE);
-        chS[0] = at_pos(S, pr >> 1, pr & 1);
-        chW[0] = at_pos(W, pr >> 1, pr & 1);
-        chS[2] = at_pos(S, pb >> 1, pb & 1);
-        chW[2] = at_pos(W, pb >> 1, pb & 1);
+        if ((pr ^ pb) == 3) {
+            // red and blue on opposite corners of the 2x2 cell (every Bayer pattern): they are the two
+            // classes of one diagonal; which diagonal follows from P ^ Q, which end from Q
+            const uint32_t dq = ((pr >> 1) ^ (pr & 1)) ? ~(mP ^ mQ) : (mP ^ mQ);  // all ones: the anti-diagonal classes
+            const uint32_t mR = (pr >> 1) ? ~mQ : mQ;                            // all ones: red is the class in row 1
+            const float s0 = selm(dq, S[0][1], S[0][0]), s1 = selm(dq, S[1][0], S[1][1]);
+            const float w0 = selm(dq, W[0][1], W[0][0]), w1 = selm(dq, W[1][0], W[1][1]);
+            chS[0] = selm(mR, s1, s0);
+            chS[2] = selm(mR, s0, s1);
+            chW[0] = selm(mR, w1, w0);
+            chW[2] = selm(mR, w0, w1);
+        } else {
+            chS[0] = at_pos(S, pr >> 1, pr & 1);
+            chW[0] = at_pos(W, pr >> 1, pr & 1);
+            chS[2] = at_pos(S, pb >> 1, pb & 1);
+            chW[2] = at_pos(W, pb >> 1, pb & 1);
+        }
         chS[1] = (totS - chS[0]) - chS[2];
         chW[1] = (totW - chW[0]) - chW[2];
     }
@@ -309,8 +335,8 @@ __global__ void __launch_bounds__(256)
             kx[k] = kp.x;
             ky[k] = kp.y;
             kz[k] = kp.z;
-            sx[k] = f2i(roundf(sh.x * 2.0f));
-            sy[k] = f2i(roundf(sh.y * 2.0f));
+            sx[k] = round2i(sh.x * 2.0f);
+            sy[k] = round2i(sh.y * 2.0f);
         }
     } else {
         // The four pixels of a strip read the same few field texels: fetch them once
@@ -355,8 +381,8 @@ __global__ void __launch_bounds__(256)
             kz[k] = lerp4(K0[ci][2], K0[ci + 1][2], K1[ci][2], K1[ci + 1][2], a, b);
             const float ux = lerp4(F0[ci][0], F0[ci + 1][0], F1[ci][0], F1[ci + 1][0], a, b);
             const float uy = lerp4(F0[ci][1], F0[ci + 1][1], F1[ci][1], F1[ci + 1][1], a, b);
-            sx[k] = f2i(roundf(ux * 2.0f));
-            sy[k] = f2i(roundf(uy * 2.0f));
+            sx[k] = round2i(ux * 2.0f);
+            sy[k] = round2i(uy * 2.0f);
         }
         safe = safe && (f2i(fy) >= 0) && (f2i(fy) + 1 <= fh - 1);
     }
@@ -445,8 +471,19 @@ template <int CFA>
 __global__ void __launch_bounds__(256, TILE_WAVES)
     k_accumulate2xTile(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
                        const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
-                       StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
+                       StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int tilesX,
+                       int tilesY, int tilesPerXcd)
 {
+    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (workgroup i -> XCD i & 7),
+    // each with its own L2.  Vertically adjacent tiles share a field-texel row, a certainty row and two
+    // raw rows; in launch order they would sit on different XCDs (30 tiles per row: i + 30 -> another
+    // XCD) and every shared row would be fetched from HBM once per tile row (measured: +190 MB of L2
+    // misses per 4K frame).  Here XCD k walks its own contiguous band of tiles in row-major order, so
+    // the shared rows are L2 hits.
+    const int pid = (int)blockIdx.x;
+    const int tile = tilesPerXcd > 0 ? (pid & 7) * tilesPerXcd + (pid >> 3) : pid;  // tilesPerXcd == 0: launch order (A/B)
+    if (tile >= tilesX * tilesY) return;  // whole workgroup (uniform), before any barrier
+    const int bIdY = tile / tilesX, bIdX = tile - bIdY * tilesX;
     __shared__ float4 sK[3][TILE_COLS];  // .w = 1 if the texel is PSD and finite, else 0
     __shared__ float2 sF[3][TILE_COLS];
     __shared__ float4 sM[3][TILE_COLS];
@@ -455,8 +492,8 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
     // accumulator staging: per wave and plane-set the wave's 3 KiB row segment, in memory order
     __shared__ __attribute__((aligned(16))) float4 sAcc[4][2][192];
     const int lx = threadIdx.x, ly = threadIdx.y;
-    const int tx = blockIdx.x * 64 + lx;
-    const int Y = blockIdx.y * 4 + ly;
+    const int tx = bIdX * 64 + lx;
+    const int Y = bIdY * 4 + ly;
     const int hrW = 2 * dimX, hrH = 2 * dimY;
     const int X0 = 4 * tx;
     const int fw = kernelParam.width, fh = kernelParam.height;  // == hrW/4, hrH/4 (checked on the host)
@@ -465,7 +502,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
         const int t = ly * 64 + lx;
         if (t < 3 * TILE_COLS) {
             const int r = t / TILE_COLS, c = t - r * TILE_COLS;
-            const int gy = (int)blockIdx.y - 1 + r, gx = (int)blockIdx.x * 64 - 1 + c;
+            const int gy = bIdY - 1 + r, gx = bIdX * 64 - 1 + c;
             const int fy = clampi(gy, 0, fh - 1), fx = clampi(gx, 0, fw - 1);
             float4 k = row_ptr((const float4*)kernelParam.ptr, kernelParam.pitch, fy)[fx];
             // a bilinear mix of PSD matrices is PSD, so admitting texels admits every pixel between them
@@ -477,7 +514,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
         }
         {
             // column t of the tile: the float path of tex_coord, texel column predicted and verified
-            const int X = (int)blockIdx.x * 256 + t;
+            const int X = bIdX * 256 + t;
             const float posX = ((float)X + 0.5f) / (float)hrW;
             float xB = posX * (float)fw - 0.5f;
             if (!finitef(xB)) xB = 0.0f;
@@ -487,20 +524,20 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
             sColA[t] = ok ? xB - fxf : -1.0f;
         }
         if (t < 4) {
-            const int Yr = (int)blockIdx.y * 4 + t;
+            const int Yr = bIdY * 4 + t;
             const float posY = ((float)Yr + 0.5f) / (float)hrH;
             float yB = posY * (float)fh - 0.5f;
             if (!finitef(yB)) yB = 0.0f;
             const float fyf = floorf(yB);
             const int frr = t < 2 ? 0 : 1;  // LDS row of texel row floor(yB)
-            const bool ok = (f2i(fyf) == (int)blockIdx.y - 1 + frr) && f2i(fyf) >= 0 && f2i(fyf) + 1 <= fh - 1;
+            const bool ok = (f2i(fyf) == bIdY - 1 + frr) && f2i(fyf) >= 0 && f2i(fyf) + 1 <= fh - 1;
             sRowB[t] = ok ? yB - fyf : -1.0f;
         }
     }
     // asynchronous global -> LDS copy of both accumulator segments; consumed only after the tap arithmetic
     const bool rowLive = Y >= STRIP_MARGIN && Y < hrH - STRIP_MARGIN;
     const size_t rowBytes = (size_t)hrW * 12;
-    const size_t segByte = (size_t)blockIdx.x * 3072;
+    const size_t segByte = (size_t)bIdX * 3072;
     char* gP = (char*)imgOut + (size_t)Y * strideOut + segByte;
     char* gW = (char*)totalWeights + (size_t)Y * strideOut + segByte;
     if (rowLive) {
@@ -545,16 +582,21 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
         const int ci = k < 2 ? 0 : 1;
         const float ux = lerp4(Ft[0][ci].x, Ft[0][ci + 1].x, Ft[1][ci].x, Ft[1][ci + 1].x, av[k], b);
         const float uy = lerp4(Ft[0][ci].y, Ft[0][ci + 1].y, Ft[1][ci].y, Ft[1][ci + 1].y, av[k], b);
-        sx[k] = f2i(roundf(ux * 2.0f));
-        sy[k] = f2i(roundf(uy * 2.0f));
+        sx[k] = round2i(ux * 2.0f);
+        sy[k] = round2i(uy * 2.0f);
         // every tap inside the frame: 0 <= q and ((q + 4) >> 1) <= dim - 1  <=>  (unsigned)q <= 2*dim - 5;
         // the range test on the rounded flow keeps saturated conversions from wrapping back into range
         const int qx = X0 + k + sx[k] - 2, qy = Y + sy[k] - 2;
         safe = safe && (uint32_t)(sx[k] + (1 << 20)) < (2u << 20) && (uint32_t)(sy[k] + (1 << 20)) < (2u << 20) &&
                (uint32_t)qx <= xmax && (uint32_t)qy <= ymax;
-        kxa[k] = lerp4(Kt[0][ci].x, Kt[0][ci + 1].x, Kt[1][ci].x, Kt[1][ci + 1].x, av[k], b);
-        kya[k] = lerp4(Kt[0][ci].y, Kt[0][ci + 1].y, Kt[1][ci].y, Kt[1][ci + 1].y, av[k], b);
-        kza[k] = lerp4(Kt[0][ci].z, Kt[0][ci + 1].z, Kt[1][ci].z, Kt[1][ci + 1].z, av[k], b);
+        // kernel parameters: same four bilinear weights, summed with fma (no rounding step depends on them)
+        const float w00 = (1.0f - av[k]) * (1.0f - b), w10 = av[k] * (1.0f - b), w01 = (1.0f - av[k]) * b, w11 = av[k] * b;
+        auto mix = [&](float t00, float t10, float t01, float t11) {
+            return __builtin_fmaf(w11, t11, __builtin_fmaf(w01, t01, __builtin_fmaf(w10, t10, w00 * t00)));
+        };
+        kxa[k] = mix(Kt[0][ci].x, Kt[0][ci + 1].x, Kt[1][ci].x, Kt[1][ci + 1].x);
+        kya[k] = mix(Kt[0][ci].y, Kt[0][ci + 1].y, Kt[1][ci].y, Kt[1][ci + 1].y);
+        kza[k] = mix(Kt[0][ci].z, Kt[0][ci + 1].z, Kt[1][ci].z, Kt[1][ci + 1].z);
     }
     float accP[12], accW[12];
 #pragma unroll
@@ -613,6 +655,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
 
 constexpr int pack_cfa(int c00, int c01, int c10, int c11) { return c00 | (c01 << 2) | (c10 << 4) | (c11 << 6); }
 
+int g_strip_xcd_remap = 1;  // MFSR_XCD_REMAP=0: tiles in launch order (A/B of the XCD-aware order)
 int g_strip_use_tile = 1;  // MFSR_STRIP_TILE: 0 register-only strip kernel, 1 LDS tile kernel (fields at HR/4)
 
 template <int CFA>
@@ -624,8 +667,12 @@ void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pi
     const bool same = kp.width == sh.width && kp.height == sh.height;
     if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4 && (dimX % 4) == 0 && (dimY % 4) == 0 &&
         g_strip_use_tile == 1)
-        hipLaunchKernelGGL((k_accumulate2xTile<CFA>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX, dimY,
-                           strideOut, strideMask, cfaPacked);
+    {
+        const int tilesX = (int)grid.x, tilesY = (int)grid.y;
+        const int tilesPerXcd = g_strip_xcd_remap ? mfsr_cdiv(tilesX * tilesY, 8) : 0;
+        hipLaunchKernelGGL((k_accumulate2xTile<CFA>), dim3(tilesPerXcd ? 8 * tilesPerXcd : tilesX * tilesY), block, 0, st, raw, imgOut, tw, mask, kp, sh, glv,
+                           lv, dimX, dimY, strideOut, strideMask, cfaPacked, tilesX, tilesY, tilesPerXcd);
+    }
     else if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4)
         hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 4>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
                            dimY, strideOut, strideMask, cfaPacked);
@@ -649,6 +696,8 @@ int mfsr_try_launch_accumulate2x_strip(const uint16_t* dataIn, mfsr_float3* imgO
     static const bool env_read = [] {
         const char* e = getenv("MFSR_STRIP_TILE");
         if (e && e[0] >= '0' && e[0] <= '1') g_strip_use_tile = e[0] - '0';
+        const char* x = getenv("MFSR_XCD_REMAP");
+        if (x && x[0] == '0') g_strip_xcd_remap = 0;
         return true;
     }();
     (void)env_read;

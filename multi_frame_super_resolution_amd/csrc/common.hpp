@@ -70,6 +70,11 @@ struct __attribute__((packed, aligned(4))) pix3 {
 // float -> int: v_cvt_i32_f32 (NaN -> 0, saturating), the CPU oracle converts the same way
 __device__ __forceinline__ int f2i(float f) { return __float2int_rz(f); }
 
+// f2i(roundf(f)) in three instructions: adding the largest float below 0.5 (with f's sign) and
+// truncating is roundf for EVERY float (half away from zero; checked exhaustively over all 2^32
+// bit patterns on the host), and v_cvt_i32_f32 is the truncation.
+__device__ __forceinline__ int round2i(float f) { return __float2int_rz(f + copysignf(0.49999997f, f)); }
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 __device__ __forceinline__ bool finitef(float v) { return fabsf(v) < __builtin_inff(); }

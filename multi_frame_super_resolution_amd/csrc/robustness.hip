@@ -28,8 +28,8 @@ __global__ void __launch_bounds__(256)
     minShift.x = fminf(s.x, shiftf.x);
     minShift.y = fminf(s.y, shiftf.y);
 
-    const int shx = f2i(roundf(shiftf.x * 0.5f));
-    const int shy = f2i(roundf(shiftf.y * 0.5f));
+    const int shx = round2i(shiftf.x * 0.5f);
+    const int shy = round2i(shiftf.y * 0.5f);
 
     pix3 pixelsRef[9];
     float mrx = 0, mry = 0, mrz = 0, mmx = 0, mmy = 0, mmz = 0;

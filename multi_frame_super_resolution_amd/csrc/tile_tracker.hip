@@ -175,8 +175,8 @@ __device__ __forceinline__ float tile_fetch(const float* __restrict__ inImg, int
     const float patchCenterY = (float)(tileIdxY * tileSize + tileSize / 2 - imgHeight / 2);
     shift.x += cf * patchCenterX - sf * patchCenterY - patchCenterX;
     shift.y += sf * patchCenterX + cf * patchCenterY - patchCenterY;
-    int pxInImgX = tileIdxX * tileSize + pxX + f2i(roundf(shift.x));
-    int pxInImgY = tileIdxY * tileSize + pxY + f2i(roundf(shift.y));
+    int pxInImgX = tileIdxX * tileSize + pxX + round2i(shift.x);
+    int pxInImgY = tileIdxY * tileSize + pxY + round2i(shift.y);
     pxInImgX = f2i(fminf(fmaxf((float)pxInImgX, 0.0f), (float)(imgWidth - 1)));
     pxInImgY = f2i(fminf(fmaxf((float)pxInImgY, 0.0f), (float)(imgHeight - 1)));
     return row_ptr(inImg, imgPitch, pxInImgY)[pxInImgX];

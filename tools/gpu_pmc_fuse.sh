@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes focused on the warp+fuse kernel (one counter group per pass).
+# SQ-only PMC passes focused on the warp+fuse kernel (one counter group per pass; TA/TCP/TCC
+# groups crash the profiler on this pool and are not collected).  Usage: tools/gpu_pmc_fuse.sh <tag>
 set -u
 tag=${1:-fuse}
 out=gpurun_out/$tag
@@ -8,13 +9,12 @@ export TMPDIR=/tmp
 B="python3 bench.py --no-cpu-baseline --steps 1 --warmup 0"
 i=0
 for grp in \
- "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
- "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_ANY" \
- "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE" \
- "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum" \
- "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" ; do
+ "SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY" \
+ "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INSTS_VMEM" \
+ "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_IFETCH SQ_BUSY_CYCLES SQ_CYCLES SQ_INSTS_SALU" ; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-include-regex "accumulate" --output-format csv -d "$out/p$i" -- $B > "$out/p$i.log" 2>&1
+  timeout -k 10 240 rocprofv3 --pmc $grp --kernel-include-regex "accumulate2x" --output-format csv -d "$out/p$i" -- $B > "$out/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/p$i.log"; exit 1; }
+  echo "pass $i done"
 done
 python3 - "$out" <<'PY'
 import csv,glob,sys,collections
@@ -23,6 +23,8 @@ agg=collections.defaultdict(list)
 for f in glob.glob(out+'/p*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         agg[r['Counter_Name']].append(float(r['Counter_Value']))
-for k,v in sorted(agg.items()):
-    print(f"{k:40s} n={len(v):3d} mean={sum(v)/len(v):.5g}")
+with open(out+'/summary.txt','w') as fo:
+    for k,v in sorted(agg.items()):
+        line=f"{k:40s} n={len(v):3d} mean={sum(v)/len(v):.6g}"
+        print(line); fo.write(line+'\n')
 PY
