@@ -474,12 +474,12 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
                        StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int tilesX,
                        int tilesY, int tilesPerXcd)
 {
-    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (workgroup i -> XCD i & 7),
-    // each with its own L2.  Vertically adjacent tiles share a field-texel row, a certainty row and two
-    // raw rows; in launch order they would sit on different XCDs (30 tiles per row: i + 30 -> another
-    // XCD) and every shared row would be fetched from HBM once per tile row (measured: +190 MB of L2
-    // misses per 4K frame).  Here XCD k walks its own contiguous band of tiles in row-major order, so
-    // the shared rows are L2 hits.
+    // Optional XCD-aware tile order (tilesPerXcd > 0).  Workgroups are dealt round-robin to the 8 XCDs
+    // (workgroup i -> XCD i & 7), each with its own L2; vertically adjacent tiles share a field-texel
+    // row, a certainty row and two raw rows but sit on different XCDs in launch order.  With the
+    // remap XCD k walks its own contiguous band of tiles in row-major order so those rows are L2
+    // hits.  Measured on MI355X: no gain (0.402 vs 0.398 ms) -- the shared rows are 5 % of the
+    // bytes and are served by the Infinity Cache either way -- so launch order is the default.
     const int pid = (int)blockIdx.x;
     const int tile = tilesPerXcd > 0 ? (pid & 7) * tilesPerXcd + (pid >> 3) : pid;  // tilesPerXcd == 0: launch order (A/B)
     if (tile >= tilesX * tilesY) return;  // whole workgroup (uniform), before any barrier
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
 
 constexpr int pack_cfa(int c00, int c01, int c10, int c11) { return c00 | (c01 << 2) | (c10 << 4) | (c11 << 6); }
 
-int g_strip_xcd_remap = 1;  // MFSR_XCD_REMAP=0: tiles in launch order (A/B of the XCD-aware order)
+int g_strip_xcd_remap = 0;  // MFSR_XCD_REMAP=1: XCD-aware tile order (measured: no gain)
 int g_strip_use_tile = 1;  // MFSR_STRIP_TILE: 0 register-only strip kernel, 1 LDS tile kernel (fields at HR/4)
 
 template <int CFA>
@@ -697,7 +697,7 @@ int mfsr_try_launch_accumulate2x_strip(const uint16_t* dataIn, mfsr_float3* imgO
         const char* e = getenv("MFSR_STRIP_TILE");
         if (e && e[0] >= '0' && e[0] <= '1') g_strip_use_tile = e[0] - '0';
         const char* x = getenv("MFSR_XCD_REMAP");
-        if (x && x[0] == '0') g_strip_xcd_remap = 0;
+        if (x && (x[0] == '0' || x[0] == '1')) g_strip_xcd_remap = x[0] - '0';
         return true;
     }();
     (void)env_read;
