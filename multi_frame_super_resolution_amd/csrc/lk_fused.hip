@@ -5,8 +5,8 @@
 // The reference runs three kernels per iteration and moves warped/Ix/Iy/It
 // through HBM (64 B/px/iter) and makes every pixel re-read its (2h+1)^2 window
 // twice.  Here one 32x16 workgroup
-//   1. warps the moved image for its tile + (h+2)-px halo straight into LDS
-//      (bilinear gather, MIRROR addressing) next to the reference tile,
+//   1. warps the moved image for its tile + (h+2)-px halo (bilinear gather, MIRROR
+//      addressing) and keeps warped + ref and warped - ref in LDS,
 //   2. forms Ix, Iy, It and the five products IxIx, IxIy, IyIy, IxIt, IyIt for
 //      the tile + h halo in LDS,
 //   3. takes the window sums separably (row pass, then column pass),
@@ -14,7 +14,8 @@
 //      updates the flow.
 // HBM traffic: 4 (ref) + 8 (flow in) + 8 (flow out) B/px plus the cached gather.
 //
-// Numerical note: the second window pass of the reference sums
+// Numerical note: Ix, Iy are taken on (warped + ref) with one *(1/24) instead of two /12 and a *0.5;
+// the window passes add in a tree shared by four neighbours; the second window pass of the reference sums
 // (M^-1 grad I) * It term by term (:311-312); the fused kernel uses the
 // algebraically identical M^-1 * sum(grad I * It).  Together with the separable
 // summation order the flow update agrees with the three-kernel chain to fp32
@@ -30,9 +31,11 @@
 #include "common.hpp"
 #include "lk_math.hpp"
 
-#define LK_TX 32
+// Tile: LK_TY rows x TX columns (template), one thread per pixel.  TX = 48 is the default: with the
+// 7x7 window the warped region (58 x 26 = 1508 samples) is 1.96 rounds of the 768 threads, where a
+// 32-wide tile needs 3 rounds of 512 for 2.13 (the warp is half of the kernel's instructions); TX = 32
+// serves images narrower than 48 + 2h + 4.
 #define LK_TY 16
-#define LK_THREADS (LK_TX * LK_TY)
 
 // reflection about the image edges for -n <= i < 2n (the tile halo never reaches further):
 // ... 1 0 | 0 1 ... n-1 | n-1 n-2 ...   (no integer division)
@@ -44,12 +47,13 @@ __device__ __forceinline__ int lk_mirror_index(int i, int n)
 
 // HT > 0: half window size known at compile time (tile geometry becomes constant, so the
 // index arithmetic of the staging loops needs no runtime integer division); HT == 0: runtime h.
-template <int HT>
-__global__ void __launch_bounds__(LK_THREADS)
+template <int HT, int LK_TX>
+__global__ void __launch_bounds__(LK_TX * LK_TY)
     k_lkIterationFused(const float2* __restrict__ shiftsIn, float2* __restrict__ shiftsOut, int pitchShift,
                        const float* __restrict__ refImg, const float* __restrict__ movedImg, int pitchImg, int width,
                        int height, int hRuntime, float minDet)
 {
+    constexpr int LK_THREADS = LK_TX * LK_TY;
     const int h = HT > 0 ? HT : hRuntime;
     extern __shared__ __attribute__((aligned(16))) float s_lk[];
     const int BW = LK_TX + 2 * h + 4, BH = LK_TY + 2 * h + 4;  // warped / ref region
@@ -68,15 +72,47 @@ __global__ void __launch_bounds__(LK_THREADS)
     texMoved.height = height;
 
     // 1. reference + warped moved image for the tile and its (h+2) halo
-    for (int i = tid; i < BW * BH; i += LK_THREADS) {
+    // Interior samples (0 <= u,v < 1, both texel pairs inside the image): mirror_coord is the identity
+    // and no index is clamped, so the fetch is four plain loads with the very same arithmetic as
+    // tex1<ADDR_MIRROR>; the few other samples are redone with the full addressing.  With the trip
+    // count known (HT > 0) the rounds are unrolled so that the loads of all rounds are in flight together.
+    auto warp_one = [&](int i, bool active) {
         const int ly = i / BW, lx = i - ly * BW;
         const int gx = lk_mirror_index(x0 + lx - h - 2, width);
         const int gy = lk_mirror_index(y0 + ly - h - 2, height);
         const float2 f = row_ptr(shiftsIn, pitchShift, gy)[gx];
+        const float rv = row_ptr(refImg, pitchImg, gy)[gx];
         const float u = ((float)gx + 0.5f + f.x) / (float)width;   // opticalFlow.cu:38-39
         const float v = ((float)gy + 0.5f + f.y) / (float)height;
-        s_wrp[i] = tex1<ADDR_MIRROR>(texMoved, u, v);
-        s_ref[i] = row_ptr(refImg, pitchImg, gy)[gx];
+        const float xB = u * (float)width - 0.5f, yB = v * (float)height - 0.5f;
+        const float fx = floorf(xB), fy = floorf(yB);
+        const int ix = f2i(fx), iy = f2i(fy);
+        const bool interior = u >= 0.0f && u < 1.0f && v >= 0.0f && v < 1.0f && (uint32_t)ix <= (uint32_t)(width - 2) &&
+                              (uint32_t)iy <= (uint32_t)(height - 2);
+        const int ixc = clampi(ix, 0, width - 2), iyc = clampi(iy, 0, height - 2);
+        const float* r0 = row_ptr(movedImg, pitchImg, iyc) + ixc;
+        const float* r1 = row_ptr(movedImg, pitchImg, iyc + 1) + ixc;
+        float wv = lerp4(r0[0], r0[1], r1[0], r1[1], xB - fx, yB - fy);
+        if (__ballot(!interior) != 0) {  // wave-uniform: only waves that touch the image border pay for it
+            const float full = tex1<ADDR_MIRROR>(texMoved, u, v);
+            wv = interior ? wv : full;
+        }
+        if (active) {
+            // the derivative stencil is linear: keep (warped + ref) for Ix, Iy and (warped - ref) = It
+            s_ref[i] = wv + rv;
+            s_wrp[i] = wv - rv;
+        }
+    };
+    if (HT > 0) {
+        constexpr int H1 = HT > 0 ? HT : 1;
+        constexpr int N1 = (LK_TX + 2 * H1 + 4) * (LK_TY + 2 * H1 + 4), R1 = (N1 + LK_THREADS - 1) / LK_THREADS;
+#pragma unroll
+        for (int r = 0; r < R1; r++) {
+            const int i = tid + r * LK_THREADS;
+            warp_one(i < N1 ? i : N1 - 1, i < N1);
+        }
+    } else {
+        for (int i = tid; i < BW * BH; i += LK_THREADS) warp_one(i, true);
     }
     __syncthreads();
 
@@ -84,31 +120,20 @@ __global__ void __launch_bounds__(LK_THREADS)
     const int planeA = AW * AH;
     for (int i = tid; i < planeA; i += LK_THREADS) {
         const int ay = i / AW, ax = i - ay * AW;
-        const float* r = s_ref + (ay + 2) * BW + (ax + 2);
-        const float* w = s_wrp + (ay + 2) * BW + (ax + 2);
+        const float* r = s_ref + (ay + 2) * BW + (ax + 2);  // warped + ref
+        // opticalFlow.cu:116-131 with source = warped, target = reference (see header note):
+        // Ix = (d(warped) + d(ref)) / 2 with d = (f[2] - 8 f[1] + 8 f[-1] - f[-2]) / 12, taken on the sum image
         float t0 = r[2];
         t0 -= r[1] * 8.0f;
         t0 += r[-1] * 8.0f;
         t0 -= r[-2];
-        t0 /= 12.0f;
-        float t1 = w[2];
-        t1 -= w[1] * 8.0f;
-        t1 += w[-1] * 8.0f;
-        t1 -= w[-2];
-        t1 /= 12.0f;
-        const float Ix = (t1 + t0) * 0.5f;  // source = warped, target = reference (see header note)
-        const float It = w[0] - r[0];       // Iz = source - target (opticalFlow.cu:131)
-        t0 = r[2 * BW];
-        t0 -= r[BW] * 8.0f;
-        t0 += r[-BW] * 8.0f;
-        t0 -= r[-2 * BW];
-        t0 /= 12.0f;
-        t1 = w[2 * BW];
-        t1 -= w[BW] * 8.0f;
-        t1 += w[-BW] * 8.0f;
-        t1 -= w[-2 * BW];
-        t1 /= 12.0f;
-        const float Iy = (t1 + t0) * 0.5f;
+        const float Ix = t0 * (1.0f / 24.0f);
+        const float It = s_wrp[(ay + 2) * BW + (ax + 2)];  // Iz = source - target (opticalFlow.cu:131)
+        float t1 = r[2 * BW];
+        t1 -= r[BW] * 8.0f;
+        t1 += r[-BW] * 8.0f;
+        t1 -= r[-2 * BW];
+        const float Iy = t1 * (1.0f / 24.0f);
         s_p[i] = Ix * Ix;
         s_p[planeA + i] = Ix * Iy;
         s_p[2 * planeA + i] = Iy * Iy;
@@ -120,41 +145,86 @@ __global__ void __launch_bounds__(LK_THREADS)
     // 3. row pass of the separable window sums
     const int planeH = LK_TX * AH;
     const int win = 2 * h + 1;
-    for (int i = tid; i < 5 * planeH; i += LK_THREADS) {
-        const int k = i / planeH;
-        const int r = i - k * planeH;
-        const int ay = r / LK_TX, x = r - ay * LK_TX;
-        const float* p = s_p + k * planeA + ay * AW + x;
-        float s = 0;
-        for (int d = 0; d < win; d++) s += p[d];
-        s_h[i] = s;
+    if (HT > 0) {
+        // four adjacent outputs per item share their loads and the sum of the common window part
+        constexpr int WIN = 2 * (HT > 0 ? HT : 1) + 1, G = LK_TX / 4;
+        for (int i = tid; i < 5 * AH * G; i += LK_THREADS) {
+            const int k = i / (AH * G);
+            const int r = i - k * (AH * G);
+            const int ay = r / G, x = (r - ay * G) * 4;
+            const float* p = s_p + k * planeA + ay * AW + x;
+            float v[WIN + 3];
+#pragma unroll
+            for (int d = 0; d < WIN + 3; d++) v[d] = p[d];
+            float o[4];
+            if (WIN >= 4) {
+                float core = v[3];
+#pragma unroll
+                for (int d = 4; d < WIN; d++) core += v[d];
+                const float l2 = v[2], l1 = v[1] + v[2], l0 = v[0] + l1;
+                const float r1 = v[WIN], r2 = r1 + v[WIN + 1], r3 = r2 + v[WIN + 2];
+                o[0] = l0 + core;
+                o[1] = (l1 + core) + r1;
+                o[2] = (l2 + core) + r2;
+                o[3] = core + r3;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float a = v[q];
+#pragma unroll
+                    for (int d = 1; d < WIN; d++) a += v[q + d];
+                    o[q] = a;
+                }
+            }
+            float* out = s_h + k * planeH + ay * LK_TX + x;
+            *(float4*)out = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    } else {
+        for (int i = tid; i < 5 * planeH; i += LK_THREADS) {
+            const int k = i / planeH;
+            const int r = i - k * planeH;
+            const int ay = r / LK_TX, x = r - ay * LK_TX;
+            const float* p = s_p + k * planeA + ay * AW + x;
+            float s = 0;
+            for (int d = 0; d < win; d++) s += p[d];
+            s_h[i] = s;
+        }
     }
     __syncthreads();
 
     // 4. column pass + solve + update
-    const int pxX = x0 + threadIdx.x, pxY = y0 + threadIdx.y;
-    if (pxX >= width || pxY >= height) return;
-    float2 shift = row_ptr(shiftsIn, pitchShift, pxY)[pxX];
-    if (!(pxX < h || pxX >= width - h || pxY < h || pxY >= height - h)) {
+    auto solve_store = [&](int pxX, int pxY, const float (&V)[5]) {
+        if (pxX >= width || pxY >= height) return;
+        float2 shift = row_ptr(shiftsIn, pitchShift, pxY)[pxX];
+        if (!(pxX < h || pxX >= width - h || pxY < h || pxY >= height - h)) {
+            float inv[4];
+            if (lk_pinv(V[0], V[1], V[2], minDet, inv)) {
+                float UV0 = inv[0] * V[3] + inv[1] * V[4];
+                float UV1 = inv[2] * V[3] + inv[3] * V[4];
+                UV0 = isnan(UV0) ? 0 : UV0;
+                UV1 = isnan(UV1) ? 0 : UV1;
+                shift.x += UV0;
+                shift.y += UV1;
+            }
+        }
+        row_ptr(shiftsOut, pitchShift, pxY)[pxX] = shift;
+    };
+    {
         float V[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const float* p = s_h + k * planeH + threadIdx.y * LK_TX + threadIdx.x;
-            float s = 0;
-            for (int d = 0; d < win; d++) s += p[d * LK_TX];
-            V[k] = s;
+            float sum = 0;
+            if (HT > 0) {
+#pragma unroll
+                for (int d = 0; d < 2 * HT + 1; d++) sum += p[d * LK_TX];
+            } else {
+                for (int d = 0; d < win; d++) sum += p[d * LK_TX];
+            }
+            V[k] = sum;
         }
-        float inv[4];
-        if (lk_pinv(V[0], V[1], V[2], minDet, inv)) {
-            float UV0 = inv[0] * V[3] + inv[1] * V[4];
-            float UV1 = inv[2] * V[3] + inv[3] * V[4];
-            UV0 = isnan(UV0) ? 0 : UV0;
-            UV1 = isnan(UV1) ? 0 : UV1;
-            shift.x += UV0;
-            shift.y += UV1;
-        }
+        solve_store(x0 + (int)threadIdx.x, y0 + (int)threadIdx.y, V);
     }
-    row_ptr(shiftsOut, pitchShift, pxY)[pxX] = shift;
 }
 
 extern "C" int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_float2* shiftsOut, int pitchShift,
@@ -167,33 +237,42 @@ extern "C" int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_
     MFSR_REQUIRE((long long)pitchShift >= 8LL * width && (pitchShift & 7) == 0 && ((uintptr_t)shiftsIn & 7) == 0 &&
                  ((uintptr_t)shiftsOut & 7) == 0);
     const int h = halfWindowSize;
-    const int BW = LK_TX + 2 * h + 4, BH = LK_TY + 2 * h + 4, AW = LK_TX + 2 * h, AH = LK_TY + 2 * h;
-    const size_t lds = sizeof(float) * ((size_t)2 * BW * BH + (size_t)5 * AW * AH + (size_t)5 * LK_TX * AH);
-    if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            MFSR_HIP_TRY(hipFuncSetAttribute((const void*)k_lkIterationFused<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             160 * 1024));
-            MFSR_HIP_TRY(hipFuncSetAttribute((const void*)k_lkIterationFused<7>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             160 * 1024));
-            attr_set = true;
-        }
-    }
+    const int TX = (width >= 48 + 2 * h + 4 && h <= 7) ? 48 : 32;
+    const int BW = TX + 2 * h + 4, BH = LK_TY + 2 * h + 4, AW = TX + 2 * h, AH = LK_TY + 2 * h;
+    const size_t lds = sizeof(float) * ((size_t)2 * BW * BH + (size_t)5 * AW * AH + (size_t)5 * TX * AH);
     if (lds > 160 * 1024) return MFSR_E_UNSUPPORTED;
-    MFSR_REQUIRE(width >= LK_TX + 2 * h + 4 && height >= LK_TY + 2 * h + 4);  // reflection range of the halo
-    dim3 block(LK_TX, LK_TY), grid(mfsr_cdiv(width, LK_TX), mfsr_cdiv(height, LK_TY));
-#define LK_LAUNCH(HT)                                                                                                  \
-    hipLaunchKernelGGL(k_lkIterationFused<HT>, grid, block, lds, mfsr_s(stream), (const float2*)shiftsIn,              \
-                       (float2*)shiftsOut, pitchShift, refImg, movedImg, pitchImg, width, height, h, minDet)
+    MFSR_REQUIRE(width >= TX + 2 * h + 4 && height >= LK_TY + 2 * h + 4);  // reflection range of the halo
+    dim3 block(TX, LK_TY), grid(mfsr_cdiv(width, TX), mfsr_cdiv(height, LK_TY));
+#define LK_LAUNCH(HT, TXV)                                                                                             \
+    do {                                                                                                               \
+        if (lds > 64 * 1024) {                                                                                         \
+            static bool attr_set = false;                                                                              \
+            if (!attr_set) {                                                                                           \
+                MFSR_HIP_TRY(hipFuncSetAttribute((const void*)k_lkIterationFused<HT, TXV>,                             \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));             \
+                attr_set = true;                                                                                       \
+            }                                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_lkIterationFused<HT, TXV>), grid, block, lds, mfsr_s(stream), (const float2*)shiftsIn,   \
+                           (float2*)shiftsOut, pitchShift, refImg, movedImg, pitchImg, width, height, h, minDet);      \
+    } while (0)
+#define LK_CASE(HT)                                                                                                    \
+    case HT:                                                                                                           \
+        if (TX == 48)                                                                                                  \
+            LK_LAUNCH(HT, 48);                                                                                         \
+        else                                                                                                           \
+            LK_LAUNCH(HT, 32);                                                                                         \
+        break;
     switch (h) {
-        case 1: LK_LAUNCH(1); break;
-        case 2: LK_LAUNCH(2); break;
-        case 3: LK_LAUNCH(3); break;
-        case 4: LK_LAUNCH(4); break;
-        case 5: LK_LAUNCH(5); break;
-        case 7: LK_LAUNCH(7); break;
-        default: LK_LAUNCH(0); break;
+        LK_CASE(1)
+        LK_CASE(2)
+        LK_CASE(3)
+        LK_CASE(4)
+        LK_CASE(5)
+        LK_CASE(7)
+        default: LK_LAUNCH(0, 32); break;
     }
+#undef LK_CASE
 #undef LK_LAUNCH
     return mfsr_launch_status("lucasKanadeIterationFused");
 }

@@ -4,28 +4,53 @@
 #pragma once
 #include "common.hpp"
 
+// cos and sin of t = atan2(y, x) / 2 without the three libm calls of the reference (:236-238,
+// :262-264): t is in [-pi/2, pi/2], so cos t >= 0 and sin t has the sign of y; the half-angle
+// identities are taken in their cancellation-free form.  Agrees with cosf/sinf(0.5f * atan2f()) to a
+// few ulp; (0, 0) gives t = 0 like atan2f, NaN propagates.
+__device__ __forceinline__ void lk_half_angle(float y, float x, float& ct, float& st)
+{
+    // v_sqrt_f32 / v_rcp_f32 / v_rsq_f32 (1 ulp) instead of the IEEE-exact expansions: this routine is
+    // a few-ulp replacement of libm calls to begin with
+    const float r = __builtin_amdgcn_sqrtf(x * x + y * y);
+    if (r == 0.0f) {
+        ct = 1.0f;
+        st = 0.0f;
+        return;
+    }
+    const float h = 0.5f * __builtin_amdgcn_rcpf(r);  // 1 / (2 r)
+    if (x >= 0.0f) {
+        ct = __builtin_amdgcn_sqrtf((r + x) * h);
+        st = y * h * __builtin_amdgcn_rcpf(ct);
+    } else {
+        const float sa = __builtin_amdgcn_sqrtf((r - x) * h);  // |sin t|
+        st = copysignf(sa, y);
+        ct = fabsf(y) * h * __builtin_amdgcn_rcpf(sa);
+    }
+}
+
 // 2x2 pseudo-inverse by closed-form SVD, shared with the fused kernel.
 // Returns false when the pixel is rejected (sigma1 < minDet, :255-257 quirk kept).
 __device__ __forceinline__ bool lk_pinv(float a, float b, float d, float minDet, float inv[4])
 {
     const float c = b;  // matMul[2] = matMul[1] (:234)
-    const float theta = 0.5f * atan2f(2.0f * a * c + 2.0f * b * d, a * a + b * b - c * c - d * d);
-    const float ct = cosf(theta);
-    const float st = sinf(theta);
+    float ct, st;
+    lk_half_angle(2.0f * a * c + 2.0f * b * d, a * a + b * b - c * c - d * d, ct, st);  // theta = atan2(..)/2 (:236-238)
     const float UT0 = ct, UT2 = -st, UT1 = st, UT3 = ct;
     const float S1 = a * a + b * b + c * c + d * d;
-    const float S2 =
-        sqrtf((a * a + b * b - c * c - d * d) * (a * a + b * b - c * c - d * d) + 4 * (a * c + b * d) * (a * c + b * d));
-    float sigma1 = sqrtf((S1 + S2) / 2);
-    float sigma2 = sqrtf((S1 - S2) / 2);
+    // v_sqrt_f32 / v_rcp_f32 (1 ulp) for sqrtf and 1/x: sigma2 comes out of a cancellation (S1 - S2)
+    // whose error dwarfs an ulp, so the IEEE-exact expansions buy nothing here
+    const float S2 = __builtin_amdgcn_sqrtf((a * a + b * b - c * c - d * d) * (a * a + b * b - c * c - d * d) +
+                                            4 * (a * c + b * d) * (a * c + b * d));
+    float sigma1 = __builtin_amdgcn_sqrtf((S1 + S2) * 0.5f);
+    float sigma2 = __builtin_amdgcn_sqrtf((S1 - S2) * 0.5f);
     const float smin = fminf(sigma1, sigma1);  // (sic) :255
     if (smin < minDet) return false;
-    sigma1 = sigma1 != 0 ? 1.0f / sigma1 : 0;
-    sigma2 = sigma2 != 0 ? 1.0f / sigma2 : 0;
+    sigma1 = sigma1 != 0 ? __builtin_amdgcn_rcpf(sigma1) : 0;
+    sigma2 = sigma2 != 0 ? __builtin_amdgcn_rcpf(sigma2) : 0;
     const float S0 = sigma1, Sb = 0, Sc = 0, S3 = sigma2;
-    const float epsilon = 0.5f * atan2f(2.0f * a * b + 2.0f * c * d, a * a - b * b + c * c - d * d);
-    const float ce = cosf(epsilon);
-    const float se = sinf(epsilon);
+    float ce, se;
+    lk_half_angle(2.0f * a * b + 2.0f * c * d, a * a - b * b + c * c - d * d, ce, se);  // epsilon (:262-264)
     float s11 = (a * ct + c * st) * ce + (b * ct + d * st) * se;
     float s22 = (a * st - c * ct) * se + (-b * st + d * ct) * ce;
     s11 = s11 > 0.0f ? 1.0f : s11 < 0 ? -1.0f : 0.0f;

@@ -13,7 +13,7 @@ for grp in \
  "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INSTS_VMEM" \
  "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_IFETCH SQ_BUSY_CYCLES SQ_CYCLES SQ_INSTS_SALU" ; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $grp --kernel-include-regex "accumulate2x" --output-format csv -d "$out/p$i" -- $B > "$out/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/p$i.log"; exit 1; }
+  timeout -k 10 240 rocprofv3 --pmc $grp --kernel-include-regex "${KERNEL_RE:-accumulate2x}" --output-format csv -d "$out/p$i" -- $B > "$out/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/p$i.log"; exit 1; }
   echo "pass $i done"
 done
 python3 - "$out" <<'PY'
