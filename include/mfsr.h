@@ -255,7 +255,12 @@ int mfsr_set_accumulate_fast_exp(int enable);
 int mfsr_trackTilesFused(const float* refImg, const float* movedImg, const mfsr_float2* preShift, int preShiftPitch,
                          mfsr_float2* coordinates, int coordinatesPitch, int imgWidth, int imgHeight, int imgPitch,
                          int maxShift, int tileSize, int tileCountX, int tileCountY, float threshold,
-                         mfsr_stream_t stream);
+                         const float* refSquaredSums, mfsr_stream_t stream);
+/* sum(ref^2) of every reference tile in the serial order of squaredSum (B3, kernel.cu:119): it does
+ * not depend on the moved frame, so a burst takes it once per reference and hands it to
+ * mfsr_trackTilesFused (refSquaredSums; NULL = taken inside the tracker). */
+int mfsr_tileSquaredSums(const float* refImg, float* outValues, int imgWidth, int imgHeight, int imgPitch, int maxShift,
+                         int tileSize, int tileCountX, int tileCountY, mfsr_stream_t stream);
 /* D2+D3+D4 for one Lucas-Kanade iteration in one launch (LDS-tiled warp,
  * derivative and separable window sums).  Flow is double-buffered: shiftsOut
  * must not alias shiftsIn (tile halos read neighbouring tiles' flow). */

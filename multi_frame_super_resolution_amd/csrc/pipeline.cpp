@@ -62,6 +62,7 @@ struct Layout {
     // unfused path scratch
     Img warped, Ix, Iy, It, rawf;
     float *refTiles, *movTiles, *cc, *boxX, *boxY, *sqsum, *dist;
+    float* refSq[kMaxLevels];  // fused tracker: sum(ref^2) per tile and level, taken once per reference
     size_t total;
 };
 
@@ -161,6 +162,9 @@ void make_layout(const mfsr_config* c, char* base, Layout* L)
         if (tiles > maxTiles) maxTiles = tiles;
         if (tiles * R * R > maxDist) maxDist = tiles * R * R;
     }
+    for (int l = 0; l < kMaxLevels; l++) L->refSq[l] = nullptr;
+    if (c->fused)
+        for (int l = 0; l < c->levels; l++) L->refSq[l] = (float*)b.take((size_t)L->tcx[l] * L->tcy[l] * 4);
     if (!c->fused) {
         L->warped = b.image(L->tw, L->th, 4);
         L->Ix = b.image(L->tw, L->th, 4);
@@ -372,6 +376,12 @@ extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, m
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
     TRY(prepare_frame(b, rawRef, L.refHalf, L.refPyr, stream));
+    if (c.fused)
+        for (int l = 0; l < c.levels; l++) {
+            const Img& ref = L.refPyr[ilog2(c.levelFactor[l])];
+            TRY(mfsr_tileSquaredSums((const float*)ref.ptr, L.refSq[l], ref.w, ref.h, ref.pitch, c.maxShift[l], c.tileSize[l],
+                                     L.tcx[l], L.tcy[l], stream));
+        }
 
     // E: kernel shape field from the reference tracking image
     if (c.fused) {
@@ -429,7 +439,7 @@ static int track_tiles(mfsr_burst* b, mfsr_stream_t stream)
         if (c.fused) {
             TRY(mfsr_trackTilesFused((const float*)ref.ptr, (const float*)mov.ptr, pre, L.pre[l].pitch,
                                      (mfsr_float2*)L.shifts[l].ptr, L.shifts[l].pitch, ref.w, ref.h, ref.pitch, S, T,
-                                     L.tcx[l], L.tcy[l], c.minimumThreshold, stream));
+                                     L.tcx[l], L.tcy[l], c.minimumThreshold, L.refSq[l], stream));
         } else {
             if (!pre) {
                 MFSR_HIP_TRY(hipMemsetAsync(L.pre[l].ptr, 0, (size_t)L.pre[l].pitch * L.pre[l].h, mfsr_s(stream)));

@@ -12,6 +12,8 @@
 //    workgroup from LDS (no FFT, no tile stacks in HBM).
 #include <cfloat>
 
+#include <cstdlib>
+
 #include "common.hpp"
 
 // ---- wavefront reductions -----------------------------------------------------
@@ -669,71 +671,167 @@ extern "C" int mfsr_fftshift(mfsr_float2* fft, int width, int height, mfsr_strea
 }
 
 // ---- fused tracker: B1+B2+B3+B4+cc+B6+B7 (+ rounded pre-shift add) --------------
-// One workgroup per tile.  Threads first gather the T x T reference template and
-// the (T+2S)^2 pre-shifted moved patch into LDS (same source-pixel rule as
-// B1/B2, base shift/rotation = 0).  Then thread k evaluates the L2 distance of
-// candidate shift k = (sy+S)*(2S+1)+(sx+S):
+// Threads gather the T x T reference template and the (T+2S)^2 pre-shifted moved patch of a
+// tile into LDS (same source-pixel rule as B1/B2, base shift/rotation = 0) and evaluate the
+// L2 distance of every candidate shift (sx, sy) in [0, 2S]^2:
 //     D = sum(ref^2) + sum_window(moved^2) - 2*sum(ref*moved)
-// with every sum taken in the order the unfused chain uses (row-major serial for
-// sum(ref^2) and the correlation; per-row sums then the sum of rows for the box
-// term), so D is bit-identical to squaredSum'(serial)/boxFilter/normalizedCC fed
-// by the direct correlation.  Wavefront 0 then reduces D with shuffles and lane 0
-// runs the quadratic sub-pixel fit.
-__global__ void __launch_bounds__(1024)
+// with every sum taken in the order the unfused chain uses (row-major serial for sum(ref^2)
+// and the correlation; per-row sums then the sum of rows for the box term), so D is
+// bit-identical to squaredSum'(serial)/boxFilter/normalizedCC fed by the direct correlation.
+//  * sum(ref^2) does not depend on the candidate or on the moved frame: it is taken once per
+//    reference (mfsr_tileSquaredSums) and passed in; without it one lane per tile takes it here.
+//  * the box term shares its row sums: rowsq[patch row][sx] is used by all 2S+1 candidates of a
+//    column, so it is tabulated first (L*(2S+1) sums of T) instead of (2S+1)^2 * T per tile.
+//  * a thread owns NSX neighbouring sx of one sy and (2S+1)*ceil((2S+1)/NSX) threads serve a tile; a
+//    workgroup packs as many tiles as fit into its 128 threads.  NSX > 1 re-uses each LDS load for
+//    NSX multiply-adds but leaves about one wavefront per SIMD at 4K (every candidate is one serial
+//    chain of T*T multiply-adds, so tiles x candidates is all the parallelism there is): measured
+//    36.6 us (NSX = 1), 59 us (2), 60 us (3) per launch, so NSX = 1 is the default (MFSR_TRK_NSX).
+// One wavefront per tile then reduces D with shuffles and lane 0 runs the quadratic fit.
+#define TRK_THREADS 128
+template <int TRK_NSX>
+__global__ void __launch_bounds__(TRK_THREADS)
     k_trackTilesFused(const float* __restrict__ refImg, const float* __restrict__ movedImg,
                       const float2* __restrict__ preShift, int preShiftPitch, float2* __restrict__ coordinates,
                       int coordinatesPitch, int imgWidth, int imgHeight, int imgPitch, int maxShift, int tileSize,
-                      int tileCountX, int tileCountY, float threshold)
+                      int tileCountX, int tileCountY, float threshold, const float* __restrict__ refSq, int tilesPerWg)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int T = tileSize, S = maxShift, L = T + 2 * S, R = 2 * S + 1;
-    float* s_ref = s_mem;            // T*T
-    float* s_mov = s_ref + T * T;    // L*L
-    float* s_dist = s_mov + L * L;   // R*R
-    const int tileIdx = blockIdx.x;
-    const int tileIdxY = tileIdx / tileCountX;
-    const int tileIdxX = tileIdx - tileIdxY * tileCountX;
+    const int Lp = L + TRK_NSX;                 // patch row stride: the last sx group may read past the row
+    const int G = (R + TRK_NSX - 1) / TRK_NSX;  // sx groups per sy
+    const int nRef = T * T, nMov = L * Lp + TRK_NSX, nRow = L * R, nDist = R * R;
+    const int slotFloats = ((nRef + nMov + nRow + nDist + 1) + 3) & ~3;
     const int tid = threadIdx.x;
-
-    float2 pre = make_float2(0.0f, 0.0f);
-    if (preShift) pre = row_ptr(preShift, preShiftPitch, tileIdxY)[tileIdxX];
+    const int tileCount = tileCountX * tileCountY;
+    const int tile0 = blockIdx.x * tilesPerWg;
     const float2 zero2 = make_float2(0.0f, 0.0f);
-    for (int i = tid; i < T * T; i += blockDim.x) {
-        const int y = i / T, x = i - y * T;
-        s_ref[i] = tile_fetch(refImg, imgWidth, imgHeight, imgPitch, T, tileIdxX, tileIdxY, x + S, y + S, zero2, zero2, 0.0f);
-    }
-    for (int i = tid; i < L * L; i += blockDim.x) {
-        const int y = i / L, x = i - y * L;
-        s_mov[i] = tile_fetch(movedImg, imgWidth, imgHeight, imgPitch, T, tileIdxX, tileIdxY, x, y, pre, zero2, 0.0f);
-    }
-    __syncthreads();
+    auto slot_ref = [&](int s) { return s_mem + s * slotFloats; };
+    auto slot_mov = [&](int s) { return s_mem + s * slotFloats + nRef; };
+    auto slot_row = [&](int s) { return s_mem + s * slotFloats + nRef + nMov; };
+    auto slot_dist = [&](int s) { return s_mem + s * slotFloats + nRef + nMov + nRow; };
+    auto slot_sq = [&](int s) { return s_mem + s * slotFloats + nRef + nMov + nRow + nDist; };
 
-    if (tid < R * R) {
-        const int sy = tid / R, sx = tid - sy * R;  // window origin in the moved patch
-        float sq = 0, cc = 0, box = 0;
-        for (int y = 0; y < T; y++) {
-            const float* mrow = s_mov + (sy + y) * L + sx;
-            const float* rrow = s_ref + y * T;
-            float rowsq = 0;
-            for (int x = 0; x < T; x++) {
-                const float r = rrow[x];
-                const float m = mrow[x];
-                sq += r * r;
-                rowsq += m * m;
-                cc += r * m;
+    // gather (tiles past the end of the grid re-read the last tile: harmless, never written back).
+    // Four independent fetches per thread and round, so their global-load latencies overlap.
+    for (int sl = 0; sl < tilesPerWg; sl++) {
+        const int tileIdx = min(tile0 + sl, tileCount - 1);
+        const int tileIdxY = tileIdx / tileCountX, tileIdxX = tileIdx - tileIdxY * tileCountX;
+        float2 pre = zero2;
+        if (preShift) pre = row_ptr(preShift, preShiftPitch, tileIdxY)[tileIdxX];
+        float* sr = slot_ref(sl);
+        float* sm = slot_mov(sl);
+        for (int j0 = tid; j0 < nRef; j0 += 4 * TRK_THREADS) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = min(j0 + u * TRK_THREADS, nRef - 1);
+                const int y = j / T, x = j - y * T;
+                v[u] = tile_fetch(refImg, imgWidth, imgHeight, imgPitch, T, tileIdxX, tileIdxY, x + S, y + S, zero2, zero2, 0.0f);
             }
-            box += rowsq;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (j0 + u * TRK_THREADS < nRef) sr[j0 + u * TRK_THREADS] = v[u];
         }
-        s_dist[tid] = sq + box - 2 * cc;
+        for (int k0 = tid; k0 < nMov; k0 += 4 * TRK_THREADS) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = min(k0 + u * TRK_THREADS, nMov - 1);
+                const int y = k / Lp, x = k - y * Lp;
+                // the pad columns / tail read a valid pixel and are zeroed below
+                const float f = tile_fetch(movedImg, imgWidth, imgHeight, imgPitch, T, tileIdxX, tileIdxY, min(x, L - 1),
+                                           min(y, L - 1), pre, zero2, 0.0f);
+                v[u] = (y < L && x < L) ? f : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (k0 + u * TRK_THREADS < nMov) sm[k0 + u * TRK_THREADS] = v[u];
+        }
     }
     __syncthreads();
 
-    if (tid < 64) {
+    // row sums of moved^2 (serial over x, as boxFilterWithBorderX) and sum(ref^2)
+    for (int i = tid; i < tilesPerWg * (nRow + 1); i += TRK_THREADS) {
+        const int sl = i / (nRow + 1), j = i - sl * (nRow + 1);
+        if (tile0 + sl >= tileCount) continue;
+        if (j < nRow) {
+            const int ry = j / R, sx = j - ry * R;
+            const float* m = slot_mov(sl) + ry * Lp + sx;
+            float a = 0;
+            for (int x = 0; x < T; x++) a += m[x] * m[x];
+            slot_row(sl)[j] = a;
+        } else if (refSq) {
+            *slot_sq(sl) = refSq[tile0 + sl];
+        } else {
+            const float* r = slot_ref(sl);
+            float a = 0;
+            for (int x = 0; x < nRef; x++) a += r[x] * r[x];
+            *slot_sq(sl) = a;
+        }
+    }
+    __syncthreads();
+
+    // correlation: thread = (tile slot, sy, group of three sx)
+    const int perTile = R * G;
+    if (tid < tilesPerWg * perTile) {
+        const int sl = tid / perTile, q = tid - sl * perTile;
+        const int sy = q / G, sx0 = (q - sy * G) * TRK_NSX;
+        if (tile0 + sl < tileCount) {
+            const float* ref = slot_ref(sl);
+            const float* mov = slot_mov(sl) + sy * Lp + sx0;
+            float cc[TRK_NSX];
+#pragma unroll
+            for (int j = 0; j < TRK_NSX; j++) cc[j] = 0;
+            for (int y = 0; y < T; y++) {
+                const float* rrow = ref + y * T;
+                const float* mrow = mov + y * Lp;
+                int x = 0;
+                for (; x + 8 <= T; x += 8) {
+                    float r[8], m[8 + TRK_NSX - 1];
+#pragma unroll
+                    for (int d = 0; d < 8; d++) r[d] = rrow[x + d];
+#pragma unroll
+                    for (int d = 0; d < 8 + TRK_NSX - 1; d++) m[d] = mrow[x + d];
+#pragma unroll
+                    for (int d = 0; d < 8; d++)
+#pragma unroll
+                        for (int j = 0; j < TRK_NSX; j++) cc[j] += r[d] * m[d + j];
+                }
+                for (; x < T; x++) {
+                    const float r = rrow[x];
+#pragma unroll
+                    for (int j = 0; j < TRK_NSX; j++) cc[j] += r * mrow[x + j];
+                }
+            }
+            const float sq = *slot_sq(sl);
+            const float* rows = slot_row(sl);
+#pragma unroll
+            for (int j = 0; j < TRK_NSX; j++) {
+                const int sx = sx0 + j;
+                if (sx < R) {
+                    float box = 0;
+                    for (int y = 0; y < T; y++) box += rows[(sy + y) * R + sx];
+                    slot_dist(sl)[sy * R + sx] = sq + box - 2 * cc[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // one wavefront per tile: min / argmin / max and the sub-pixel fit
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int sl = wave; sl < tilesPerWg; sl += TRK_THREADS / 64) {
+        const int tileIdx = tile0 + sl;
+        if (tileIdx >= tileCount) continue;
         float minVal, maxVal;
         int minIdx;
-        wave_min_argmin_max(s_dist, R * R, tid, minVal, minIdx, maxVal);
-        if (tid == 0) {
-            float2 coord = subpixel_minimum(s_dist, S, minVal, minIdx, maxVal, threshold);
+        wave_min_argmin_max(slot_dist(sl), R * R, lane, minVal, minIdx, maxVal);
+        if (lane == 0) {
+            const int tileIdxY = tileIdx / tileCountX, tileIdxX = tileIdx - tileIdxY * tileCountX;
+            float2 pre = zero2;
+            if (preShift) pre = row_ptr(preShift, preShiftPitch, tileIdxY)[tileIdxX];
+            float2 coord = subpixel_minimum(slot_dist(sl), S, minVal, minIdx, maxVal, threshold);
             coord.x = roundf(pre.x) + coord.x;
             coord.y = roundf(pre.y) + coord.y;
             row_ptr(coordinates, coordinatesPitch, tileIdxY)[tileIdxX] = coord;
@@ -741,10 +839,44 @@ __global__ void __launch_bounds__(1024)
     }
 }
 
+// sum(ref^2) per tile in the serial row-major order of squaredSum' (B3): once per reference frame
+__global__ void __launch_bounds__(64)
+    k_tileSquaredSums(const float* __restrict__ refImg, float* __restrict__ out, int imgWidth, int imgHeight, int imgPitch,
+                      int maxShift, int tileSize, int tileCountX, int tileCountY)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const int T = tileSize, S = maxShift;
+    const int tileIdx = blockIdx.x;
+    const int tileIdxY = tileIdx / tileCountX, tileIdxX = tileIdx - tileIdxY * tileCountX;
+    const float2 zero2 = make_float2(0.0f, 0.0f);
+    for (int i = threadIdx.x; i < T * T; i += 64) {
+        const int y = i / T, x = i - y * T;
+        s_mem[i] = tile_fetch(refImg, imgWidth, imgHeight, imgPitch, T, tileIdxX, tileIdxY, x + S, y + S, zero2, zero2, 0.0f);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0;
+        for (int i = 0; i < T * T; i++) a += s_mem[i] * s_mem[i];
+        out[tileIdx] = a;
+    }
+}
+
+extern "C" int mfsr_tileSquaredSums(const float* refImg, float* outValues, int imgWidth, int imgHeight, int imgPitch,
+                                    int maxShift, int tileSize, int tileCountX, int tileCountY, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(refImg && outValues && imgWidth > 0 && imgHeight > 0);
+    MFSR_REQUIRE((long long)imgPitch >= 4LL * imgWidth && (imgPitch & 3) == 0);
+    MFSR_REQUIRE(maxShift >= 1 && maxShift <= 15 && tileSize >= 4 && tileSize <= 128 && tileCountX > 0 && tileCountY > 0);
+    hipLaunchKernelGGL(k_tileSquaredSums, dim3(tileCountX * tileCountY), dim3(64), sizeof(float) * tileSize * tileSize,
+                       mfsr_s(stream), refImg, outValues, imgWidth, imgHeight, imgPitch, maxShift, tileSize, tileCountX,
+                       tileCountY);
+    return mfsr_launch_status("tileSquaredSums");
+}
+
 extern "C" int mfsr_trackTilesFused(const float* refImg, const float* movedImg, const mfsr_float2* preShift,
                                     int preShiftPitch, mfsr_float2* coordinates, int coordinatesPitch, int imgWidth,
                                     int imgHeight, int imgPitch, int maxShift, int tileSize, int tileCountX,
-                                    int tileCountY, float threshold, mfsr_stream_t stream)
+                                    int tileCountY, float threshold, const float* refSquaredSums, mfsr_stream_t stream)
 {
     MFSR_REQUIRE(refImg && movedImg && coordinates && imgWidth > 0 && imgHeight > 0);
     MFSR_REQUIRE((long long)imgPitch >= 4LL * imgWidth && (imgPitch & 3) == 0);
@@ -753,12 +885,31 @@ extern "C" int mfsr_trackTilesFused(const float* refImg, const float* movedImg, 
                  ((uintptr_t)coordinates & 7) == 0);
     if (preShift)
         MFSR_REQUIRE((long long)preShiftPitch >= 8LL * tileCountX && (preShiftPitch & 7) == 0 && ((uintptr_t)preShift & 7) == 0);
-    const int L = tileSize + 2 * maxShift, R = 2 * maxShift + 1;
-    const size_t lds = sizeof(float) * ((size_t)tileSize * tileSize + (size_t)L * L + (size_t)R * R);
+    static const int nsx = [] {
+        const char* e = getenv("MFSR_TRK_NSX");
+        return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 1;
+    }();
+    const int TRK_NSX = nsx;
+    const int T = tileSize, L = T + 2 * maxShift, R = 2 * maxShift + 1, Lp = L + TRK_NSX;
+    const int G = (R + TRK_NSX - 1) / TRK_NSX;
+    if (R * G > TRK_THREADS) return MFSR_E_UNSUPPORTED;
+    const int slotFloats = ((T * T + L * Lp + TRK_NSX + L * R + R * R + 1) + 3) & ~3;
+    int tilesPerWg = TRK_THREADS / (R * G);
+    while (tilesPerWg > 1 && sizeof(float) * (size_t)slotFloats * tilesPerWg > 56 * 1024) tilesPerWg--;
+    const size_t lds = sizeof(float) * (size_t)slotFloats * tilesPerWg;
     if (lds > 64 * 1024) return MFSR_E_UNSUPPORTED;
-    const int threads = ((R * R + 63) / 64) * 64;
-    hipLaunchKernelGGL(k_trackTilesFused, dim3(tileCountX * tileCountY), dim3(threads), lds, mfsr_s(stream), refImg,
-                       movedImg, (const float2*)preShift, preShiftPitch, (float2*)coordinates, coordinatesPitch, imgWidth,
-                       imgHeight, imgPitch, maxShift, tileSize, tileCountX, tileCountY, threshold);
+    const int tiles = tileCountX * tileCountY;
+#define TRK_LAUNCH(N)                                                                                                  \
+    hipLaunchKernelGGL(k_trackTilesFused<N>, dim3(mfsr_cdiv(tiles, tilesPerWg)), dim3(TRK_THREADS), lds, mfsr_s(stream),  \
+                       refImg, movedImg, (const float2*)preShift, preShiftPitch, (float2*)coordinates, coordinatesPitch, \
+                       imgWidth, imgHeight, imgPitch, maxShift, tileSize, tileCountX, tileCountY, threshold,           \
+                       refSquaredSums, tilesPerWg)
+    if (nsx == 1)
+        TRK_LAUNCH(1);
+    else if (nsx == 2)
+        TRK_LAUNCH(2);
+    else
+        TRK_LAUNCH(3);
+#undef TRK_LAUNCH
     return mfsr_launch_status("trackTilesFused");
 }

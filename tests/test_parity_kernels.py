@@ -383,8 +383,15 @@ def test_trackTilesFused_equals_chain(orc, hip, T, S):
     orc.call("findMinimum", dist, coord, pitch_of(coord), S, n, tcx, 0.0)
     orc.call("addRoundedPreShift", pre, pitch_of(pre), coord, pitch_of(coord), tcx, tcy)
     got = np.zeros((tcy, tcx, 2), np.float32)
-    hip.call("trackTilesFused", ref, mov, pre, pitch_of(pre), got, pitch_of(got), W, H, pitch_of(ref), S, T, tcx, tcy, 0.0)
+    hip.call("trackTilesFused", ref, mov, pre, pitch_of(pre), got, pitch_of(got), W, H, pitch_of(ref), S, T, tcx, tcy, 0.0, None)
     assert_bitexact(coord, got, "trackTilesFused")
+    # sum(ref^2) taken once per reference (tileSquaredSums) and handed in: same bits as squaredSum (B3)
+    sq2 = np.zeros(n, np.float32)
+    hip.call("tileSquaredSums", ref, sq2, W, H, pitch_of(ref), S, T, tcx, tcy)
+    assert_bitexact(sq, sq2, "tileSquaredSums")
+    got2 = np.zeros((tcy, tcx, 2), np.float32)
+    hip.call("trackTilesFused", ref, mov, pre, pitch_of(pre), got2, pitch_of(got2), W, H, pitch_of(ref), S, T, tcx, tcy, 0.0, sq2)
+    assert_bitexact(coord, got2, "trackTilesFused(refSquaredSums)")
     # interior tiles whose residual (truth - round(pre)) lies strictly inside the search range
     # recover the true shift (-1, +2); on the border ring findMinimum returns 0 (kernel.cu:548-553)
     res = np.array([-1.0, 2.0]) - np.round(pre)
