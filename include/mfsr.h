@@ -110,6 +110,15 @@ int mfsr_accumulateSuperResFull(const uint16_t* dataIn, mfsr_float3* imgOut, mfs
                                 mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int scale,
                                 int strideOut, int strideMask, mfsr_stream_t stream);
 
+/* Two frames in one call (frame 0, then frame 1): what two mfsr_accumulateSuperResFull calls compute,
+ * with the accumulators read and written once where the x2 tile kernel applies.  Equal to the
+ * two-call sequence to fp32 rounding (the two per-pixel sums are added to each other first). */
+int mfsr_accumulateSuperResFull2(const uint16_t* dataIn0, const uint16_t* dataIn1, mfsr_float3* imgOut,
+                                 mfsr_float3* totalWeights, const mfsr_float4* certaintyMask0,
+                                 const mfsr_float4* certaintyMask1, mfsr_tex2d kernelParam, mfsr_tex2d shifts0,
+                                 mfsr_tex2d shifts1, mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY,
+                                 int scale, int strideOut, int strideMask, mfsr_stream_t stream);
+
 /* ---- B/E/H/I: kernel.cu --------------------------------------------------- */
 int mfsr_squaredSum(const float* inTiles, float* outValues, int maxShift, int tileSize, int tileCount,
                     mfsr_stream_t stream); /* :119 */
@@ -310,7 +319,8 @@ typedef struct {
     float weightThreshold;
     int32_t applyGamma;
     int32_t fused;           /* 1: fused MI355X kernels; 0: one launch per reference kernel */
-    int32_t reserved[7];
+    int32_t pairFrames;      /* 1: add_frame fuses frames two at a time (see mfsr_burst_add_frame) */
+    int32_t reserved[6];
 } mfsr_config;
 
 typedef struct mfsr_burst mfsr_burst;
@@ -328,9 +338,16 @@ void mfsr_burst_destroy(mfsr_burst* b);
 int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, mfsr_stream_t stream);
 /* Align + robustness + accumulate ONE frame into the caller's accumulators
  * (float3 HR, pitch 12*scale*width; zeroed by the caller before the first
- * call).  isReference != 0: identity flow, certainty 1. */
+ * call).  isReference != 0: identity flow, certainty 1.
+ * With cfg.pairFrames the warp+fuse of a frame is deferred until the next frame is aligned and
+ * both are fused in one pass over the accumulators (half the accumulator traffic): after an
+ * odd number of calls one frame is still waiting -- its raw buffer must stay untouched and the
+ * accumulators do not contain it -- until the next add_frame, mfsr_burst_flush, finish or
+ * finish_rows has been issued on the stream. */
 int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float3* imgOut,
                          mfsr_float3* totalWeights, mfsr_stream_t stream);
+/* fuse a frame that is still waiting for its partner (no-op otherwise) */
+int mfsr_burst_flush(mfsr_burst* b, mfsr_stream_t stream);
 /* ApplyWeighting (+fallback) + optional gamma; outImg float3 HR (may be NULL),
  * out16 dense interleaved u16 HR (may be NULL). */
 int mfsr_burst_finish(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights, mfsr_float3* outImg,
@@ -342,9 +359,10 @@ int mfsr_burst_finish_rows(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_
                            mfsr_float3* outImg, uint16_t* out16, int row0, int rows, mfsr_stream_t stream);
 /* HIP-event timing of the warp+fuse (accumulate) launches made by add_frame on
  * the caller's stream: timing(b,1) starts a series, timing_read synchronises with
- * the events and returns the summed kernel milliseconds and the launch count. */
+ * the events and returns the summed kernel milliseconds, the launch count and the
+ * number of frames those launches fused (2 per launch with pairFrames). */
 int mfsr_burst_timing(mfsr_burst* b, int enable);
-int mfsr_burst_timing_read(mfsr_burst* b, double* totalMs, int* launches);
+int mfsr_burst_timing_read(mfsr_burst* b, double* totalMs, int* launches, int* frames);
 /* last per-frame flow field (tracking resolution, raw-pixel units) and mask,
  * for tests: returns device pointers valid until the next add_frame */
 int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2d* mask, mfsr_tex2d* kernelParam,

@@ -103,10 +103,11 @@ extern "C" int mfsr_set_accumulate_fast_exp(int enable)
     return MFSR_OK;
 }
 
-int mfsr_try_launch_accumulate2x_strip(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
-                                       const mfsr_float4* certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts,
-                                       mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int strideOut,
-                                       int strideMask, mfsr_stream_t stream);  // accumulate_fast.hip
+int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
+                                       mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
+                                       mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
+                                       mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
+                                       mfsr_stream_t stream);  // accumulate_fast.hip
 
 static int check_superres_args(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
                                const mfsr_float4* certaintyMask, const mfsr_tex2d& kernelParam, const mfsr_tex2d& shifts,
@@ -153,7 +154,7 @@ extern "C" int mfsr_accumulateSuperResFull(const uint16_t* dataIn, mfsr_float3* 
                                  dimX * scale, strideOut, strideMask);
     if (rc) return rc;
     if (g_accumulate_fast == 2 && scale == 2 &&
-        mfsr_try_launch_accumulate2x_strip(dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, whiteLevel,
+        mfsr_try_launch_accumulate2x_strip(1, &dataIn, imgOut, totalWeights, &certaintyMask, kernelParam, &shifts, whiteLevel,
                                            blackLevel, dimX, dimY, strideOut, strideMask, stream) == 1)
         return mfsr_launch_status("accumulateSuperResFull(strip)");
     dim3 block(64, 4), grid(mfsr_cdiv((long long)dimX * scale, 64), mfsr_cdiv((long long)dimY * scale, 4));
@@ -167,4 +168,36 @@ extern "C" int mfsr_accumulateSuperResFull(const uint16_t* dataIn, mfsr_float3* 
                            (pix3*)imgOut, (pix3*)totalWeights, (const float4*)certaintyMask, kernelParam, shifts, lv, dimX,
                            dimY, scale, strideOut, strideMask, mfsr_cfa_packed());
     return mfsr_launch_status("accumulateSuperResFull");
+}
+
+// Two frames onto the same accumulators in one call: what two successive
+// mfsr_accumulateSuperResFull calls compute (frame 0 then frame 1), with the accumulators read and
+// written once when the x2 LDS tile kernel serves the geometry (24 instead of 48 B per HR pixel and
+// frame).  The per-pixel sums of the two frames are added to each other before they are added to the
+// accumulator, so results equal the two-call sequence to fp32 rounding, not bit for bit.
+extern "C" int mfsr_accumulateSuperResFull2(const uint16_t* dataIn0, const uint16_t* dataIn1, mfsr_float3* imgOut,
+                                            mfsr_float3* totalWeights, const mfsr_float4* certaintyMask0,
+                                            const mfsr_float4* certaintyMask1, mfsr_tex2d kernelParam, mfsr_tex2d shifts0,
+                                            mfsr_tex2d shifts1, mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX,
+                                            int dimY, int scale, int strideOut, int strideMask, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(scale >= 1 && scale <= 8);
+    int rc = check_superres_args(dataIn0, imgOut, totalWeights, certaintyMask0, kernelParam, shifts0, dimX, dimY, dimX * scale,
+                                 strideOut, strideMask);
+    if (rc) return rc;
+    rc = check_superres_args(dataIn1, imgOut, totalWeights, certaintyMask1, kernelParam, shifts1, dimX, dimY, dimX * scale,
+                             strideOut, strideMask);
+    if (rc) return rc;
+    const uint16_t* raws[2] = {dataIn0, dataIn1};
+    const mfsr_float4* masks[2] = {certaintyMask0, certaintyMask1};
+    const mfsr_tex2d sh[2] = {shifts0, shifts1};
+    if (g_accumulate_fast == 2 && scale == 2 &&
+        mfsr_try_launch_accumulate2x_strip(2, raws, imgOut, totalWeights, masks, kernelParam, sh, whiteLevel, blackLevel, dimX,
+                                           dimY, strideOut, strideMask, stream) == 1)
+        return mfsr_launch_status("accumulateSuperResFull2(strip)");
+    rc = mfsr_accumulateSuperResFull(dataIn0, imgOut, totalWeights, certaintyMask0, kernelParam, shifts0, whiteLevel, blackLevel,
+                                     dimX, dimY, scale, strideOut, strideMask, stream);
+    if (rc) return rc;
+    return mfsr_accumulateSuperResFull(dataIn1, imgOut, totalWeights, certaintyMask1, kernelParam, shifts1, whiteLevel,
+                                       blackLevel, dimX, dimY, scale, strideOut, strideMask, stream);
 }

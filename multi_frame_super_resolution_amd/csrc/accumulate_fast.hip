@@ -464,15 +464,33 @@ __global__ void __launch_bounds__(256)
 //    arithmetic), are updated in LDS and written back in memory order: every accumulator access
 //    on the HBM side is a fully used 128-byte line.
 #define TILE_COLS 66
+// waves per SIMD the register budget is sized for: 3 (one frame, 168 VGPRs, no spills; measured
+// faster than 4 waves with spills) and 2 (two frames per launch)
 #ifndef TILE_WAVES
-#define TILE_WAVES 4
+#define TILE_WAVES 3
 #endif
-template <int CFA>
-__global__ void __launch_bounds__(256, TILE_WAVES)
-    k_accumulate2xTile(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
-                       const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
-                       StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int tilesX,
-                       int tilesY, int tilesPerXcd)
+#ifndef TILE_WAVES2
+#define TILE_WAVES2 2
+#endif
+#define TILE_WAVES_NF(NF) ((NF) == 1 ? TILE_WAVES : TILE_WAVES2)
+// NF frames per launch (1 or 2).  Everything that does not depend on the frame is done once for
+// both: the accumulator staging and write-back (the 48 B/px/frame of HBM traffic become 24), the
+// kernel-parameter mix, the column/row fractions.  The two frames add into the same registers.
+struct TileFrame {
+    const uint16_t* raw;
+    const float4* mask;
+    mfsr_tex2d shifts;
+};
+template <int NF>
+struct TileFrames {
+    TileFrame f[NF];
+};
+
+template <int CFA, int NF>
+__global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
+    k_accumulate2xTile(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
+                       Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked,
+                       int tilesX, int tilesY, int tilesPerXcd)
 {
     // Optional XCD-aware tile order (tilesPerXcd > 0).  Workgroups are dealt round-robin to the 8 XCDs
     // (workgroup i -> XCD i & 7), each with its own L2; vertically adjacent tiles share a field-texel
@@ -485,8 +503,8 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
     if (tile >= tilesX * tilesY) return;  // whole workgroup (uniform), before any barrier
     const int bIdY = tile / tilesX, bIdX = tile - bIdY * tilesX;
     __shared__ float4 sK[3][TILE_COLS];  // .w = 1 if the texel is PSD and finite, else 0
-    __shared__ float2 sF[3][TILE_COLS];
-    __shared__ float4 sM[3][TILE_COLS];
+    __shared__ float2 sF[NF][3][TILE_COLS];
+    __shared__ float4 sM[NF][3][TILE_COLS];
     __shared__ __attribute__((aligned(16))) float sColA[256];  // x fraction per HR column of the tile, -1 = not on the predicted texel
     __shared__ float sRowB[4];                                 // y fraction per HR row of the tile, -1 likewise
     // accumulator staging: per wave and plane-set the wave's 3 KiB row segment, in memory order
@@ -508,9 +526,12 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
             // a bilinear mix of PSD matrices is PSD, so admitting texels admits every pixel between them
             k.w = psd_ok(k.x, k.y, k.z) ? 1.0f : 0.0f;
             sK[r][c] = k;
-            sF[r][c] = row_ptr((const float2*)shifts.ptr, shifts.pitch, fy)[fx];
-            const float4 m = row_ptr(certaintyMask, strideMask, clampi(gy, 0, mh - 1))[clampi(gx, 0, mw - 1)];
-            sM[r][c] = make_float4(sane(m.x), sane(m.y), sane(m.z), 0.0f);
+#pragma unroll
+            for (int n = 0; n < NF; n++) {
+                sF[n][r][c] = row_ptr((const float2*)fr.f[n].shifts.ptr, fr.f[n].shifts.pitch, fy)[fx];
+                const float4 m = row_ptr(fr.f[n].mask, strideMask, clampi(gy, 0, mh - 1))[clampi(gx, 0, mw - 1)];
+                sM[n][r][c] = make_float4(sane(m.x), sane(m.y), sane(m.z), 0.0f);
+            }
         }
         {
             // column t of the tile: the float path of tex_coord, texel column predicted and verified
@@ -556,68 +577,85 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
     if (!rowLive) return;
     const bool stripLive = X0 >= STRIP_MARGIN && X0 < hrW - STRIP_MARGIN;
 
-    const int fr = ly < 2 ? 0 : 1;
+    const int fr_ = ly < 2 ? 0 : 1;
     const float b = sRowB[ly];
     const float4 av4 = ((const float4*)sColA)[lx];
     const float av[4] = {av4.x, av4.y, av4.z, av4.w};
-    bool safe = stripLive && b >= 0.0f && fminf(fminf(av[0], av[1]), fminf(av[2], av[3])) >= 0.0f;
+    const bool geomOk = stripLive && b >= 0.0f && fminf(fminf(av[0], av[1]), fminf(av[2], av[3])) >= 0.0f;
 
-    // texels of this strip: 3 columns x 2 rows
-    float4 Kt[2][3];
-    float2 Ft[2][3];
-#pragma unroll
-    for (int r = 0; r < 2; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            Kt[r][c] = sK[fr + r][lx + c];
-            Ft[r][c] = sF[fr + r][lx + c];
-        }
-    safe = safe && (((Kt[0][0].w * Kt[0][1].w) * (Kt[0][2].w * Kt[1][0].w)) * (Kt[1][1].w * Kt[1][2].w) > 0.0f);
-
-    int sx[4], sy[4];
+    // kernel parameters of this strip (frame independent): 3 columns x 2 rows of texels
     float kxa[4], kya[4], kza[4];
-    const uint32_t xmax = (uint32_t)(2 * dimX - 5), ymax = (uint32_t)(2 * dimY - 5);
+    bool kOk;
+    {
+        float4 Kt[2][3];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int ci = k < 2 ? 0 : 1;
-        const float ux = lerp4(Ft[0][ci].x, Ft[0][ci + 1].x, Ft[1][ci].x, Ft[1][ci + 1].x, av[k], b);
-        const float uy = lerp4(Ft[0][ci].y, Ft[0][ci + 1].y, Ft[1][ci].y, Ft[1][ci + 1].y, av[k], b);
-        sx[k] = round2i(ux * 2.0f);
-        sy[k] = round2i(uy * 2.0f);
-        // every tap inside the frame: 0 <= q and ((q + 4) >> 1) <= dim - 1  <=>  (unsigned)q <= 2*dim - 5;
-        // the range test on the rounded flow keeps saturated conversions from wrapping back into range
-        const int qx = X0 + k + sx[k] - 2, qy = Y + sy[k] - 2;
-        safe = safe && (uint32_t)(sx[k] + (1 << 20)) < (2u << 20) && (uint32_t)(sy[k] + (1 << 20)) < (2u << 20) &&
-               (uint32_t)qx <= xmax && (uint32_t)qy <= ymax;
-        // kernel parameters: same four bilinear weights, summed with fma (no rounding step depends on them)
-        const float w00 = (1.0f - av[k]) * (1.0f - b), w10 = av[k] * (1.0f - b), w01 = (1.0f - av[k]) * b, w11 = av[k] * b;
-        auto mix = [&](float t00, float t10, float t01, float t11) {
-            return __builtin_fmaf(w11, t11, __builtin_fmaf(w01, t01, __builtin_fmaf(w10, t10, w00 * t00)));
-        };
-        kxa[k] = mix(Kt[0][ci].x, Kt[0][ci + 1].x, Kt[1][ci].x, Kt[1][ci + 1].x);
-        kya[k] = mix(Kt[0][ci].y, Kt[0][ci + 1].y, Kt[1][ci].y, Kt[1][ci + 1].y);
-        kza[k] = mix(Kt[0][ci].z, Kt[0][ci + 1].z, Kt[1][ci].z, Kt[1][ci + 1].z);
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) Kt[r][c] = sK[fr_ + r][lx + c];
+        kOk = ((Kt[0][0].w * Kt[0][1].w) * (Kt[0][2].w * Kt[1][0].w)) * (Kt[1][1].w * Kt[1][2].w) > 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int ci = k < 2 ? 0 : 1;
+            // same four bilinear weights as the flow, summed with fma (no rounding step depends on them)
+            const float w00 = (1.0f - av[k]) * (1.0f - b), w10 = av[k] * (1.0f - b), w01 = (1.0f - av[k]) * b, w11 = av[k] * b;
+            auto mix = [&](float t00, float t10, float t01, float t11) {
+                return __builtin_fmaf(w11, t11, __builtin_fmaf(w01, t01, __builtin_fmaf(w10, t10, w00 * t00)));
+            };
+            kxa[k] = mix(Kt[0][ci].x, Kt[0][ci + 1].x, Kt[1][ci].x, Kt[1][ci + 1].x);
+            kya[k] = mix(Kt[0][ci].y, Kt[0][ci + 1].y, Kt[1][ci].y, Kt[1][ci + 1].y);
+            kza[k] = mix(Kt[0][ci].z, Kt[0][ci + 1].z, Kt[1][ci].z, Kt[1][ci + 1].z);
+        }
     }
+
     float accP[12], accW[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) accP[i] = accW[i] = 0.0f;
+    const uint32_t xmax = (uint32_t)(2 * dimX - 5), ymax = (uint32_t)(2 * dimY - 5);
+    uint32_t safeBits = 0;  // bit n: frame n took the fast path
+#pragma unroll
+    for (int n = 0; n < NF; n++) {
+        float2 Ft[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) Ft[r][c] = sF[n][fr_ + r][lx + c];
+        int sx[4], sy[4];
+        bool safe = geomOk && kOk;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int ci = k < 2 ? 0 : 1;
+            const float ux = lerp4(Ft[0][ci].x, Ft[0][ci + 1].x, Ft[1][ci].x, Ft[1][ci + 1].x, av[k], b);
+            const float uy = lerp4(Ft[0][ci].y, Ft[0][ci + 1].y, Ft[1][ci].y, Ft[1][ci + 1].y, av[k], b);
+            sx[k] = round2i(ux * 2.0f);
+            sy[k] = round2i(uy * 2.0f);
+            // every tap inside the frame: 0 <= q and ((q + 4) >> 1) <= dim - 1  <=>  (unsigned)q <= 2*dim - 5;
+            // the range test on the rounded flow keeps saturated conversions from wrapping back into range
+            const int qx = X0 + k + sx[k] - 2, qy = Y + sy[k] - 2;
+            safe = safe && (uint32_t)(sx[k] + (1 << 20)) < (2u << 20) && (uint32_t)(sy[k] + (1 << 20)) < (2u << 20) &&
+                   (uint32_t)qx <= xmax && (uint32_t)qy <= ymax;
+        }
+        if (safe) {
+            safeBits |= 1u << n;
+            // certainty: LDS row of the mask row that tap row jt reads = ((ly + jt - 2) >> 2) + 1; column lx + cell
+            auto mval = [&](int jt, int cell, int ch) {
+                const int mr = ((ly + jt - 2) >> 2) + 1;
+                const float* p = (const float*)&sM[n][mr][lx + cell];
+                return p[ch];
+            };
+            const uint16_t* raw = fr.f[n].raw;
+            strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
+            strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
+            strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
+            strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
+        }
+        // one frame after the other: interleaving the two bodies only costs registers
+        __builtin_amdgcn_sched_barrier(0);
+    }
     float* myP = (float*)&sAcc[ly][0][0] + lx * 12;  // this lane's 4 pixels x 3 channels inside the staged segment
     float* myW = (float*)&sAcc[ly][1][0] + lx * 12;
-    if (safe) {
-        // certainty: LDS row of the mask row that tap row jt reads = ((ly + jt - 2) >> 2) + 1; column lx + cell
-        auto mval = [&](int jt, int cell, int ch) {
-            const int mr = ((ly + jt - 2) >> 2) + 1;
-            const float* p = (const float*)&sM[mr][lx + cell];
-            return p[ch];
-        };
-        strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
-        strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
-        strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
-        strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
-    }
     // staged accumulators must have landed before anyone reads them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (safe) {
+    if (safeBits) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             float4 a = ((float4*)myP)[j], c = ((float4*)myW)[j];
@@ -626,18 +664,22 @@ __global__ void __launch_bounds__(256, TILE_WAVES)
             ((float4*)myP)[j] = a;
             ((float4*)myW)[j] = c;
         }
-    } else if (stripLive) {
-        // border / wild-flow / non-PSD strips: the straight per-pixel arithmetic on the staged values
+    }
+#pragma unroll
+    for (int n = 0; n < NF; n++) {
+        if (!((safeBits >> n) & 1u) && stripLive) {
+            // border / wild-flow / non-PSD strips: the straight per-pixel arithmetic on the staged values
 #pragma unroll 1
-        for (int k = 0; k < 4; k++) {
-            const int X = X0 + k;
-            if (X >= 1 && X < hrW - 1) {
-                pix3 px = {myP[3 * k], myP[3 * k + 1], myP[3 * k + 2]};
-                pix3 tw = {myW[3 * k], myW[3 * k + 1], myW[3 * k + 2]};
-                accumulate_pixel_core<GEOM_FULL, true>(X, Y, raw, certaintyMask, kernelParam, shifts, glv, dimX, dimY, 2,
-                                                       strideMask, cfaPacked, px, tw);
-                myP[3 * k] = px.x; myP[3 * k + 1] = px.y; myP[3 * k + 2] = px.z;
-                myW[3 * k] = tw.x; myW[3 * k + 1] = tw.y; myW[3 * k + 2] = tw.z;
+            for (int k = 0; k < 4; k++) {
+                const int X = X0 + k;
+                if (X >= 1 && X < hrW - 1) {
+                    pix3 px = {myP[3 * k], myP[3 * k + 1], myP[3 * k + 2]};
+                    pix3 tw = {myW[3 * k], myW[3 * k + 1], myW[3 * k + 2]};
+                    accumulate_pixel_core<GEOM_FULL, true>(X, Y, fr.f[n].raw, fr.f[n].mask, kernelParam, fr.f[n].shifts, glv,
+                                                           dimX, dimY, 2, strideMask, cfaPacked, px, tw);
+                    myP[3 * k] = px.x; myP[3 * k + 1] = px.y; myP[3 * k + 2] = px.z;
+                    myW[3 * k] = tw.x; myW[3 * k + 1] = tw.y; myW[3 * k + 2] = tw.z;
+                }
             }
         }
     }
@@ -658,6 +700,24 @@ constexpr int pack_cfa(int c00, int c01, int c10, int c11) { return c00 | (c01 <
 int g_strip_xcd_remap = 0;  // MFSR_XCD_REMAP=1: XCD-aware tile order (measured: no gain)
 int g_strip_use_tile = 1;  // MFSR_STRIP_TILE: 0 register-only strip kernel, 1 LDS tile kernel (fields at HR/4)
 
+// true when the LDS tile kernel serves this geometry (fields at HR/4, whole tiles)
+bool tile_kernel_ok(mfsr_tex2d kp, mfsr_tex2d sh, int dimX, int dimY)
+{
+    const int hrW = 2 * dimX, hrH = 2 * dimY;
+    return kp.width == sh.width && kp.height == sh.height && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4 &&
+           (dimX % 4) == 0 && (dimY % 4) == 0 && g_strip_use_tile == 1;
+}
+
+template <int CFA, int NF>
+void launch_tile(dim3 grid, dim3 block, hipStream_t st, const TileFrames<NF>& fr, pix3* imgOut, pix3* tw, mfsr_tex2d kp,
+                 Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
+{
+    const int tilesX = (int)grid.x, tilesY = (int)grid.y;
+    const int tilesPerXcd = g_strip_xcd_remap ? mfsr_cdiv(tilesX * tilesY, 8) : 0;
+    hipLaunchKernelGGL((k_accumulate2xTile<CFA, NF>), dim3(tilesPerXcd ? 8 * tilesPerXcd : tilesX * tilesY), block, 0, st, fr,
+                       imgOut, tw, kp, glv, lv, dimX, dimY, strideOut, strideMask, cfaPacked, tilesX, tilesY, tilesPerXcd);
+}
+
 template <int CFA>
 void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pix3* imgOut, pix3* tw, const float4* mask,
                   mfsr_tex2d kp, mfsr_tex2d sh, Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut,
@@ -665,15 +725,13 @@ void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pi
 {
     const int hrW = 2 * dimX, hrH = 2 * dimY;
     const bool same = kp.width == sh.width && kp.height == sh.height;
-    if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4 && (dimX % 4) == 0 && (dimY % 4) == 0 &&
-        g_strip_use_tile == 1)
-    {
-        const int tilesX = (int)grid.x, tilesY = (int)grid.y;
-        const int tilesPerXcd = g_strip_xcd_remap ? mfsr_cdiv(tilesX * tilesY, 8) : 0;
-        hipLaunchKernelGGL((k_accumulate2xTile<CFA>), dim3(tilesPerXcd ? 8 * tilesPerXcd : tilesX * tilesY), block, 0, st, raw, imgOut, tw, mask, kp, sh, glv,
-                           lv, dimX, dimY, strideOut, strideMask, cfaPacked, tilesX, tilesY, tilesPerXcd);
-    }
-    else if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4)
+    if (tile_kernel_ok(kp, sh, dimX, dimY)) {
+        TileFrames<1> fr;
+        fr.f[0].raw = raw;
+        fr.f[0].mask = mask;
+        fr.f[0].shifts = sh;
+        launch_tile<CFA, 1>(grid, block, st, fr, imgOut, tw, kp, glv, lv, dimX, dimY, strideOut, strideMask, cfaPacked);
+    } else if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4)
         hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 4>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
                            dimY, strideOut, strideMask, cfaPacked);
     else if (same && kp.width * 2 == hrW && kp.height * 2 == hrH && kp.width >= 4)
@@ -684,14 +742,7 @@ void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pi
                            dimY, strideOut, strideMask, cfaPacked);
 }
 
-}  // namespace
-
-// Returns 1 if the strip kernel was launched, 0 if the configuration is not one it
-// handles (caller falls back to the straight kernel), < 0 never.
-int mfsr_try_launch_accumulate2x_strip(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
-                                       const mfsr_float4* certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts,
-                                       mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int strideOut,
-                                       int strideMask, mfsr_stream_t stream)
+void read_env_once()
 {
     static const bool env_read = [] {
         const char* e = getenv("MFSR_STRIP_TILE");
@@ -701,6 +752,22 @@ int mfsr_try_launch_accumulate2x_strip(const uint16_t* dataIn, mfsr_float3* imgO
         return true;
     }();
     (void)env_read;
+}
+
+}  // namespace
+
+// Returns 1 if the fast kernels were launched for all `nFrames` (1 or 2) frames, 0 if the
+// configuration is not one they handle (caller falls back to the straight kernel), < 0 never.
+// With two frames the LDS tile kernel fuses both in one pass over the accumulators; the other
+// geometries run frame after frame.
+int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
+                                       mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
+                                       mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
+                                       mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
+                                       mfsr_stream_t stream)
+{
+    read_env_once();
+    if (nFrames < 1 || nFrames > 2) return 0;
     int cfa[4];
     mfsr_get_cfa_pattern(cfa);
     for (int i = 0; i < 4; i++)
@@ -723,19 +790,35 @@ int mfsr_try_launch_accumulate2x_strip(const uint16_t* dataIn, mfsr_float3* imgO
     hipStream_t st = mfsr_s(stream);
     pix3* pI = (pix3*)imgOut;
     pix3* pT = (pix3*)totalWeights;
-    const float4* pM = (const float4*)certaintyMask;
     const int cp = mfsr_cfa_packed();
-    auto launch_margin = [&]() {
+    const bool pair = nFrames == 2 && tile_kernel_ok(kernelParam, shifts[0], dimX, dimY) &&
+                      tile_kernel_ok(kernelParam, shifts[1], dimX, dimY);
+    auto launch_margin = [&](int n) {
         const int M = STRIP_MARGIN;
-        const long long n = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
-        hipLaunchKernelGGL(k_accumulateMargin, dim3(mfsr_cdiv(n, 256)), dim3(256), 0, st, dataIn, pI, pT, pM, kernelParam,
-                           shifts, glv, dimX, dimY, strideOut, strideMask, cp);
+        const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
+        hipLaunchKernelGGL(k_accumulateMargin, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, st, dataIn[n], pI, pT,
+                           (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp);
     };
 #define STRIP_CASE(a, b, c, d)                                                                                         \
     case pack_cfa(a, b, c, d):                                                                                         \
-        launch_strip<pack_cfa(a, b, c, d)>(grid, block, st, dataIn, pI, pT, pM, kernelParam, shifts, glv, lv, dimX, dimY, \
-                                          strideOut, strideMask, cp);                                                  \
-        launch_margin();                                                                                               \
+        if (pair) {                                                                                                    \
+            TileFrames<2> fr;                                                                                          \
+            for (int n = 0; n < 2; n++) {                                                                              \
+                fr.f[n].raw = dataIn[n];                                                                               \
+                fr.f[n].mask = (const float4*)certaintyMask[n];                                                        \
+                fr.f[n].shifts = shifts[n];                                                                            \
+            }                                                                                                          \
+            launch_tile<pack_cfa(a, b, c, d), 2>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY, strideOut, \
+                                                 strideMask, cp);                                                      \
+            launch_margin(0);                                                                                          \
+            launch_margin(1);                                                                                          \
+        } else {                                                                                                       \
+            for (int n = 0; n < nFrames; n++) {                                                                        \
+                launch_strip<pack_cfa(a, b, c, d)>(grid, block, st, dataIn[n], pI, pT, (const float4*)certaintyMask[n], \
+                                                  kernelParam, shifts[n], glv, lv, dimX, dimY, strideOut, strideMask, cp); \
+                launch_margin(n);                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
         return 1;
     switch (packed2) {
         STRIP_CASE(MFSR_RED, MFSR_GREEN, MFSR_GREEN, MFSR_BLUE)   // RGGB

@@ -56,8 +56,8 @@ struct Layout {
     Img tensor, tensorTmp, tensorSm;         // float3, tracking res
     Img fallback;                            // float3, W x H
     Img tmpA, tmpB;                          // float, tracking res
-    Img flowA, flowB;                        // float2, tracking res
-    Img mask;                                // float4, half res
+    Img flowBuf[3];                          // float2, tracking res: two for the LK ping-pong + the flow of a frame waiting for its pair
+    Img maskBuf[2];                          // float4, half res (current frame / frame waiting for its pair)
     Img shifts[kMaxLevels], pre[kMaxLevels]; // float2, tile grids
     // unfused path scratch
     Img warped, Ix, Iy, It, rawf;
@@ -143,9 +143,8 @@ void make_layout(const mfsr_config* c, char* base, Layout* L)
     L->fallback = b.image(L->W, L->H, 12);
     L->tmpA = b.image(L->tw, L->th, 4);
     L->tmpB = b.image(L->tw, L->th, 4);
-    L->flowA = b.image(L->tw, L->th, 8);
-    L->flowB = b.image(L->tw, L->th, 8);
-    L->mask = b.image(L->hw, L->hh, 16);
+    for (int i = 0; i < 3; i++) L->flowBuf[i] = b.image(L->tw, L->th, 8);
+    for (int i = 0; i < 2; i++) L->maskBuf[i] = b.image(L->hw, L->hh, 16);
     size_t maxTileFloats = 0, maxTiles = 0, maxDist = 0;
     for (int l = 0; l < c->levels; l++) {
         const int f = c->levelFactor[l];
@@ -202,7 +201,18 @@ struct mfsr_burst {
     float tensorTaps[99];
     int ntensorTaps;
     Img* flowCur;  // flow of the last add_frame (raw-pixel units)
+    Img* maskCur;  // certainty mask of the last add_frame
     bool haveRef;
+    // frame pairing (cfg.pairFrames): an aligned frame waits here until the next one is aligned, then
+    // both are fused in one pass over the accumulators; flush/finish fuses a frame left alone
+    struct Pending {
+        bool has;
+        const uint16_t* raw;
+        Img* flow;
+        Img* mask;
+        mfsr_float3 *imgOut, *totalWeights;
+    } pend;
+    int nFramesTimed;
     // optional per-launch timing of the accumulate kernel (bench.py roofline leg)
     bool timing;
     int nEvents;
@@ -214,6 +224,9 @@ struct mfsr_burst {
         int rc_ = (expr);          \
         if (rc_ != MFSR_OK) return rc_; \
     } while (0)
+
+static int flush_pending(mfsr_burst* b, mfsr_stream_t stream);
+
 
 extern "C" int mfsr_config_default(mfsr_config* cfg, int width, int height, int frames, int scale, int mono)
 {
@@ -264,6 +277,7 @@ extern "C" int mfsr_config_default(mfsr_config* cfg, int width, int height, int 
     cfg->weightThreshold = 1e-3f;
     cfg->applyGamma = 0;
     cfg->fused = 1;
+    cfg->pairFrames = 1;
     return MFSR_OK;
 }
 
@@ -301,7 +315,10 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     }
     b->ntaps = mfsr_gaussin_filter_1D(cfg->sigmaTracking, b->taps);
     b->ntensorTaps = mfsr_gaussin_filter_1D(cfg->sigmaTensor, b->tensorTaps);
-    b->flowCur = &b->L.flowA;
+    b->flowCur = &b->L.flowBuf[0];
+    b->maskCur = &b->L.maskBuf[0];
+    b->pend.has = false;
+    b->nFramesTimed = 0;
     b->haveRef = false;
     b->timing = false;
     b->nEvents = 0;
@@ -328,14 +345,15 @@ extern "C" int mfsr_burst_timing(mfsr_burst* b, int enable)
     MFSR_REQUIRE(b != nullptr);
     b->timing = enable != 0;
     b->nEvents = 0;
+    b->nFramesTimed = 0;
     return MFSR_OK;
 }
 
 // Synchronises with the recorded events and returns the summed kernel time and
 // the number of timed launches since mfsr_burst_timing(b, 1).
-extern "C" int mfsr_burst_timing_read(mfsr_burst* b, double* totalMs, int* launches)
+extern "C" int mfsr_burst_timing_read(mfsr_burst* b, double* totalMs, int* launches, int* frames)
 {
-    MFSR_REQUIRE(b && totalMs && launches);
+    MFSR_REQUIRE(b && totalMs && launches && frames);
     double total = 0;
     for (int i = 0; i < b->nEvents; i++) {
         MFSR_HIP_TRY(hipEventSynchronize(b->evStop[i]));
@@ -345,7 +363,9 @@ extern "C" int mfsr_burst_timing_read(mfsr_burst* b, double* totalMs, int* launc
     }
     *totalMs = total;
     *launches = b->nEvents;
+    *frames = b->nFramesTimed;
     b->nEvents = 0;
+    b->nFramesTimed = 0;
     return MFSR_OK;
 }
 
@@ -373,6 +393,7 @@ static int prepare_frame(mfsr_burst* b, const uint16_t* raw, Img& half, Img* pyr
 extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, mfsr_stream_t stream)
 {
     MFSR_REQUIRE(b && rawRef);
+    TRY(flush_pending(b, stream));  // a frame still waiting belongs to the previous reference
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
     TRY(prepare_frame(b, rawRef, L.refHalf, L.refPyr, stream));
@@ -463,6 +484,46 @@ static int track_tiles(mfsr_burst* b, mfsr_stream_t stream)
     return MFSR_OK;
 }
 
+// G: one or two aligned frames onto the caller's accumulators (timed with HIP events on request)
+static int accumulate_frames(mfsr_burst* b, int n, const uint16_t* raw0, const uint16_t* raw1, Img* flow0, Img* flow1,
+                             Img* mask0, Img* mask1, mfsr_float3* imgOut, mfsr_float3* totalWeights, mfsr_stream_t stream)
+{
+    const mfsr_config& c = b->cfg;
+    Layout& L = b->L;
+    const mfsr_float3 white = {c.white[0], c.white[1], c.white[2]};
+    const mfsr_float3 black = {c.black[0], c.black[1], c.black[2]};
+    const int strideOut = 12 * L.hrW;
+    TRY(mfsr_set_cfa_pattern(c.cfa));
+    const bool timed = b->timing && b->nEvents < kMaxTimedLaunches;
+    if (timed) {
+        const int i = b->nEvents;
+        if (!b->evStart[i]) MFSR_HIP_TRY(hipEventCreate(&b->evStart[i]));
+        if (!b->evStop[i]) MFSR_HIP_TRY(hipEventCreate(&b->evStop[i]));
+        MFSR_HIP_TRY(hipEventRecord(b->evStart[i], mfsr_s(stream)));
+    }
+    if (n == 2)
+        TRY(mfsr_accumulateSuperResFull2(raw0, raw1, imgOut, totalWeights, (const mfsr_float4*)mask0->ptr,
+                                         (const mfsr_float4*)mask1->ptr, as_tex(L.kparam4), as_tex(*flow0), as_tex(*flow1),
+                                         white, black, L.W, L.H, c.scale, strideOut, mask0->pitch, stream));
+    else
+        TRY(mfsr_accumulateSuperResFull(raw0, imgOut, totalWeights, (const mfsr_float4*)mask0->ptr, as_tex(L.kparam4),
+                                        as_tex(*flow0), white, black, L.W, L.H, c.scale, strideOut, mask0->pitch, stream));
+    if (timed) {
+        MFSR_HIP_TRY(hipEventRecord(b->evStop[b->nEvents], mfsr_s(stream)));
+        b->nEvents++;
+        b->nFramesTimed += n;
+    }
+    return MFSR_OK;
+}
+
+static int flush_pending(mfsr_burst* b, mfsr_stream_t stream)
+{
+    if (!b->pend.has) return MFSR_OK;
+    mfsr_burst::Pending p = b->pend;
+    b->pend.has = false;
+    return accumulate_frames(b, 1, p.raw, nullptr, p.flow, nullptr, p.mask, nullptr, p.imgOut, p.totalWeights, stream);
+}
+
 extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float3* imgOut,
                                     mfsr_float3* totalWeights, mfsr_stream_t stream)
 {
@@ -470,24 +531,31 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
     MFSR_REQUIRE(b->haveRef);
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
-    const mfsr_float3 white = {c.white[0], c.white[1], c.white[2]};
-    const mfsr_float3 black = {c.black[0], c.black[1], c.black[2]};
-    const int strideOut = 12 * L.hrW;
     TRY(mfsr_set_cfa_pattern(c.cfa));
 
-    Img* flow = &L.flowA;
+    // buffers of this frame: the two flow buffers and the mask buffer a waiting frame does not hold
+    Img* flow = nullptr;
+    Img* other = nullptr;
+    for (int i = 0; i < 3; i++) {
+        Img* f = &L.flowBuf[i];
+        if (b->pend.has && f == b->pend.flow) continue;
+        if (!flow)
+            flow = f;
+        else if (!other)
+            other = f;
+    }
+    Img* mask = (b->pend.has && b->pend.mask == &L.maskBuf[0]) ? &L.maskBuf[1] : &L.maskBuf[0];
     if (isReference) {
         // identity flow, certainty 1
-        MFSR_HIP_TRY(hipMemsetAsync(L.flowA.ptr, 0, (size_t)L.flowA.pitch * L.flowA.h, mfsr_s(stream)));
-        TRY(mfsr_fill_f32((float*)L.mask.ptr, (size_t)L.mask.pitch / 4 * L.mask.h, 1.0f, stream));
+        MFSR_HIP_TRY(hipMemsetAsync(flow->ptr, 0, (size_t)flow->pitch * flow->h, mfsr_s(stream)));
+        TRY(mfsr_fill_f32((float*)mask->ptr, (size_t)mask->pitch / 4 * mask->h, 1.0f, stream));
     } else {
         TRY(prepare_frame(b, raw, L.movHalf, L.movPyr, stream));
         TRY(track_tiles(b, stream));
         const int last = c.levels - 1;
         const mfsr_float2 zero2 = {0.0f, 0.0f};
-        TRY(mfsr_CreateFlowFieldFromTiles((mfsr_float2*)L.flowA.ptr, as_tex(L.shifts[last]), c.tileSize[last], L.tcx[last],
-                                          L.tcy[last], L.tw, L.th, L.flowA.pitch, zero2, 0.0f, stream));
-        Img* other = &L.flowB;
+        TRY(mfsr_CreateFlowFieldFromTiles((mfsr_float2*)flow->ptr, as_tex(L.shifts[last]), c.tileSize[last], L.tcx[last],
+                                          L.tcy[last], L.tw, L.th, flow->pitch, zero2, 0.0f, stream));
         for (int it = 0; it < c.lkIterations; it++) {
             if (c.fused) {
                 TRY(mfsr_lucasKanadeIterationFused((const mfsr_float2*)flow->ptr, (mfsr_float2*)other->ptr, flow->pitch,
@@ -512,27 +580,36 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
         if (L.flowScale != 1)
             TRY(mfsr_scaleFlow((mfsr_float2*)flow->ptr, flow->pitch, L.tw, L.th, (float)L.flowScale, stream));
         // F: robustness mask (1-px ring is never written by the kernel -> pre-zero)
-        MFSR_HIP_TRY(hipMemsetAsync(L.mask.ptr, 0, (size_t)L.mask.pitch * L.mask.h, mfsr_s(stream)));
+        MFSR_HIP_TRY(hipMemsetAsync(mask->ptr, 0, (size_t)mask->pitch * mask->h, mfsr_s(stream)));
         TRY(mfsr_ComputeRobustnessMask((const mfsr_float3*)L.refHalf.ptr, (const mfsr_float3*)L.movHalf.ptr,
-                                       (mfsr_float4*)L.mask.ptr, as_tex(*flow), L.hw, L.hh, L.refHalf.pitch, L.mask.pitch,
+                                       (mfsr_float4*)mask->ptr, as_tex(*flow), L.hw, L.hh, L.refHalf.pitch, mask->pitch,
                                        c.alpha, c.beta, c.thresholdM, stream));
     }
     b->flowCur = flow;
-    // G: accumulate onto the HR grid
-    const bool timed = b->timing && b->nEvents < kMaxTimedLaunches;
-    if (timed) {
-        const int i = b->nEvents;
-        if (!b->evStart[i]) MFSR_HIP_TRY(hipEventCreate(&b->evStart[i]));
-        if (!b->evStop[i]) MFSR_HIP_TRY(hipEventCreate(&b->evStop[i]));
-        MFSR_HIP_TRY(hipEventRecord(b->evStart[i], mfsr_s(stream)));
+    b->maskCur = mask;
+    // G: accumulate onto the HR grid -- alone, or together with the frame that was waiting for a partner
+    if (b->pend.has && (b->pend.imgOut != imgOut || b->pend.totalWeights != totalWeights)) TRY(flush_pending(b, stream));
+    if (b->pend.has) {
+        mfsr_burst::Pending p = b->pend;
+        b->pend.has = false;
+        return accumulate_frames(b, 2, p.raw, raw, p.flow, flow, p.mask, mask, imgOut, totalWeights, stream);
     }
-    TRY(mfsr_accumulateSuperResFull(raw, imgOut, totalWeights, (const mfsr_float4*)L.mask.ptr, as_tex(L.kparam4),
-                                    as_tex(*flow), white, black, L.W, L.H, c.scale, strideOut, L.mask.pitch, stream));
-    if (timed) {
-        MFSR_HIP_TRY(hipEventRecord(b->evStop[b->nEvents], mfsr_s(stream)));
-        b->nEvents++;
+    if (c.pairFrames) {
+        b->pend.has = true;
+        b->pend.raw = raw;
+        b->pend.flow = flow;
+        b->pend.mask = mask;
+        b->pend.imgOut = imgOut;
+        b->pend.totalWeights = totalWeights;
+        return MFSR_OK;
     }
-    return MFSR_OK;
+    return accumulate_frames(b, 1, raw, nullptr, flow, nullptr, mask, nullptr, imgOut, totalWeights, stream);
+}
+
+extern "C" int mfsr_burst_flush(mfsr_burst* b, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b != nullptr);
+    return flush_pending(b, stream);
 }
 
 extern "C" int mfsr_burst_finish(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights,
@@ -540,6 +617,7 @@ extern "C" int mfsr_burst_finish(mfsr_burst* b, const mfsr_float3* imgOut, const
 {
     MFSR_REQUIRE(b && imgOut && totalWeights && (outImg || out16));
     MFSR_REQUIRE(b->haveRef);
+    TRY(flush_pending(b, stream));
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
     const int pitch = 12 * L.hrW;
@@ -568,6 +646,7 @@ extern "C" int mfsr_burst_finish_rows(mfsr_burst* b, const mfsr_float3* imgOut, 
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
     MFSR_REQUIRE(row0 >= 0 && rows > 0 && row0 + rows <= L.hrH);
+    TRY(flush_pending(b, stream));
     const int pitch = 12 * L.hrW;
     const float v0 = (float)row0 / (float)L.hrH, v1 = (float)(row0 + rows) / (float)L.hrH;
     const size_t off = (size_t)row0 * pitch;
@@ -584,7 +663,7 @@ extern "C" int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2
 {
     MFSR_REQUIRE(b != nullptr);
     if (flow) *flow = as_tex(*b->flowCur);
-    if (mask) *mask = as_tex(b->L.mask);
+    if (mask) *mask = as_tex(*b->maskCur);
     if (kernelParam) *kernelParam = as_tex(b->L.kparam4);
     if (tracking) *tracking = as_tex(b->L.refPyr[0]);
     return MFSR_OK;

@@ -774,8 +774,8 @@ __global__ void __launch_bounds__(TRK_THREADS)
 
     // correlation: thread = (tile slot, sy, group of three sx)
     const int perTile = R * G;
-    if (tid < tilesPerWg * perTile) {
-        const int sl = tid / perTile, q = tid - sl * perTile;
+    for (int item = tid; item < tilesPerWg * perTile; item += TRK_THREADS) {
+        const int sl = item / perTile, q = item - sl * perTile;
         const int sy = q / G, sx0 = (q - sy * G) * TRK_NSX;
         if (tile0 + sl < tileCount) {
             const float* ref = slot_ref(sl);
@@ -892,9 +892,8 @@ extern "C" int mfsr_trackTilesFused(const float* refImg, const float* movedImg, 
     const int TRK_NSX = nsx;
     const int T = tileSize, L = T + 2 * maxShift, R = 2 * maxShift + 1, Lp = L + TRK_NSX;
     const int G = (R + TRK_NSX - 1) / TRK_NSX;
-    if (R * G > TRK_THREADS) return MFSR_E_UNSUPPORTED;
     const int slotFloats = ((T * T + L * Lp + TRK_NSX + L * R + R * R + 1) + 3) & ~3;
-    int tilesPerWg = TRK_THREADS / (R * G);
+    int tilesPerWg = TRK_THREADS / (R * G) > 0 ? TRK_THREADS / (R * G) : 1;  // large search ranges: several rounds per tile
     while (tilesPerWg > 1 && sizeof(float) * (size_t)slotFloats * tilesPerWg > 56 * 1024) tilesPerWg--;
     const size_t lds = sizeof(float) * (size_t)slotFloats * tilesPerWg;
     if (lds > 64 * 1024) return MFSR_E_UNSUPPORTED;

@@ -41,9 +41,9 @@ class BurstPipeline:
             self.hr_w, self.hr_h = cfg.width * cfg.scale, cfg.height * cfg.scale
             # accumulators: float3 HR, pitch 12*hrW (caller-owned, RMW across frames,
             # reference DeBayerKernels.cu:306-307,374-375)
-            self.img_out = torch.zeros(self.hr_h, self.hr_w, 3, dtype=torch.float32, device=self.device)
-            self.total_weights = torch.zeros_like(self.img_out)
-            self.out_img = torch.empty_like(self.img_out)
+            self._img_out = torch.zeros(self.hr_h, self.hr_w, 3, dtype=torch.float32, device=self.device)
+            self._total_weights = torch.zeros_like(self._img_out)
+            self.out_img = torch.empty_like(self._img_out)
             self.out16 = torch.empty(self.hr_h, self.hr_w, 3, dtype=torch.int16, device=self.device)
             handle = ctypes.c_void_p()
             self.L.burst_create(ctypes.byref(handle), ctypes.byref(cfg), self._ws_ptr, nbytes)
@@ -64,9 +64,25 @@ class BurstPipeline:
     def _stream() -> int:
         return torch.cuda.current_stream().cuda_stream
 
+    # With cfg.pairFrames (the default) add_frame defers the warp+fuse of every other frame until its
+    # partner is aligned (mfsr.h, mfsr_burst_add_frame): readers of the accumulators flush first.
+    def flush(self):
+        self.L.burst_flush(self._h, self._stream())
+
+    @property
+    def img_out(self) -> torch.Tensor:
+        self.flush()
+        return self._img_out
+
+    @property
+    def total_weights(self) -> torch.Tensor:
+        self.flush()
+        return self._total_weights
+
     def reset_accumulators(self):
-        self.img_out.zero_()
-        self.total_weights.zero_()
+        self.flush()
+        self._img_out.zero_()
+        self._total_weights.zero_()
 
     def set_reference(self, raw: torch.Tensor):
         self._check_raw(raw)
@@ -74,11 +90,11 @@ class BurstPipeline:
 
     def add_frame(self, raw: torch.Tensor, is_reference: bool = False):
         self._check_raw(raw)
-        self.L.burst_add_frame(self._h, raw.data_ptr(), 1 if is_reference else 0, self.img_out.data_ptr(),
-                               self.total_weights.data_ptr(), self._stream())
+        self.L.burst_add_frame(self._h, raw.data_ptr(), 1 if is_reference else 0, self._img_out.data_ptr(),
+                               self._total_weights.data_ptr(), self._stream())
 
     def finish(self, want_float: bool = True, want_u16: bool = True):
-        self.L.burst_finish(self._h, self.img_out.data_ptr(), self.total_weights.data_ptr(),
+        self.L.burst_finish(self._h, self._img_out.data_ptr(), self._total_weights.data_ptr(),
                             self.out_img.data_ptr() if want_float else None,
                             self.out16.data_ptr() if want_u16 else None, self._stream())
         return (self.out_img if want_float else None), (self.out16 if want_u16 else None)
@@ -86,7 +102,7 @@ class BurstPipeline:
     def finish_rows(self, row0: int, rows: int) -> torch.Tensor:
         """Finish only HR rows [row0, row0+rows) (reduce-scatter mode); returns the
         full-size u16 buffer with that stripe filled."""
-        self.L.burst_finish_rows(self._h, self.img_out.data_ptr(), self.total_weights.data_ptr(), None,
+        self.L.burst_finish_rows(self._h, self._img_out.data_ptr(), self._total_weights.data_ptr(), None,
                                  self.out16.data_ptr(), row0, rows, self._stream())
         return self.out16
 

@@ -206,6 +206,41 @@ def test_accumulate_x2_strip_kernel(orc, hip, pat, field):
     assert not np.array_equal(res[2][0], res[1][0]) or pat == "MONO"   # the strip path really ran
 
 
+@pytest.mark.parametrize("field", ["quarter", "half"])
+@pytest.mark.parametrize("pat", ["RGGB", "GBRG", "MONO"])
+def test_accumulate_x2_two_frames_per_call(orc, hip, pat, field):
+    """accumulateSuperResFull2 (two frames, one pass over the accumulators) == two oracle calls.
+    quarter-resolution fields take the fused LDS tile kernel, half-resolution ones the per-frame path."""
+    W, H, s = 192, 96, 2
+    cfa = [1, 1, 1, 1] if pat == "MONO" else PATTERNS[pat]
+    orc.set_cfa(cfa)
+    hip.set_cfa(cfa)
+    white, black = F3([3839, 3700, 3900]), F3([256, 260, 250])
+    fh, fw = {"quarter": (H // 2, W // 2), "half": (H, W)}[field]
+
+    def make():
+        raw0, imgOut, tw, mask0 = _accum_inputs(120, W, H, W * s, H * s, nan_frac=0.01)
+        raw1, _, _, mask1 = _accum_inputs(121, W, H, W * s, H * s, nan_frac=0.01)
+        kp = _kernel_field(122, fh, fw, 4)
+        # smooth-ish flows (many strips on the fast path) with a wild patch and a NaN texel
+        yy, xx = np.mgrid[0:fh, 0:fw].astype(np.float32)
+        sh0 = np.stack([1.3 + 0.01 * xx, -2.2 + 0.02 * yy], -1).astype(np.float32)
+        sh1 = np.stack([-3.6 - 0.015 * yy, 0.4 + 0.01 * xx], -1).astype(np.float32)
+        sh0[10:14, 10:14] = 1e9
+        sh1[20, 20] = np.nan
+        return raw0, raw1, imgOut, tw, mask0, mask1, kp, sh0, sh1
+
+    raw0, raw1, oi, ow, m0, m1, kp, sh0, sh1 = make()
+    for raw, m, sh in ((raw0, m0, sh0), (raw1, m1, sh1)):
+        orc.call("accumulateSuperResFull", raw, oi, ow, m, Tex(kp), Tex(sh), white, black, W, H, s, pitch_of(oi), pitch_of(m))
+    raw0, raw1, hi, hw_, m0, m1, kp, sh0, sh1 = make()
+    hip.call("accumulateSuperResFull2", raw0, raw1, hi, hw_, m0, m1, Tex(kp), Tex(sh0), Tex(sh1), white, black, W, H, s,
+             pitch_of(hi), pitch_of(m0))
+    np.testing.assert_allclose(hi, oi, rtol=3e-5, atol=3e-5)
+    np.testing.assert_allclose(hw_, ow, rtol=3e-5, atol=3e-5)
+    assert np.abs(hw_).max() > 0.5
+
+
 def test_accumulateImages_x1(orc, hip):
     W, H = 64, 40
     orc.set_cfa(RGGB)

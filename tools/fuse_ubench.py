@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--shift", type=float, nargs=2, default=[1.3, -2.6])
+    ap.add_argument("--pair", action="store_true", help="two frames per call (mfsr_accumulateSuperResFull2)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     L = capi.lib()
@@ -70,9 +71,18 @@ def main():
     white, black = capi.Float3(3839, 3839, 3839), capi.Float3(256, 256, 256)
     L.set_cfa_pattern((ctypes.c_int * 4)(0, 1, 1, 2))
 
+    raw2 = torch.roll(raw, (3, 5), (0, 1)).contiguous()
+    mask2 = torch.rand(fh, fw, 4, device=dev, generator=g)
+    sh2 = (sh + torch.tensor([0.7, 1.9], device=dev)).contiguous()
+
     def launch():
-        L.accumulateSuperResFull(raw.data_ptr(), img.data_ptr(), tw.data_ptr(), mask.data_ptr(), tex(kp, 16), tex(sh, 8),
-                                 white, black, W, H, 2, hw * 12, fw * 16, None)
+        if args.pair:
+            L.accumulateSuperResFull2(raw.data_ptr(), raw2.data_ptr(), img.data_ptr(), tw.data_ptr(), mask.data_ptr(),
+                                      mask2.data_ptr(), tex(kp, 16), tex(sh, 8), tex(sh2, 8), white, black, W, H, 2, hw * 12,
+                                      fw * 16, None)
+        else:
+            L.accumulateSuperResFull(raw.data_ptr(), img.data_ptr(), tw.data_ptr(), mask.data_ptr(), tex(kp, 16), tex(sh, 8),
+                                     white, black, W, H, 2, hw * 12, fw * 16, None)
 
     for _ in range(3):
         launch()
@@ -85,7 +95,9 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.iters
     nbytes = hw * hh * 48 + W * H * 2 + fw * fh * (16 + 8 + 16)
-    print(f"tile={os.environ.get('MFSR_STRIP_TILE', 'default')} flow={args.flow} texel-neighbour-same={same:.3f} "
+    if args.pair:
+        nbytes *= 2   # algorithmic bytes: two frame units per call
+    print(f"pair={int(args.pair)} tile={os.environ.get('MFSR_STRIP_TILE', 'default')} flow={args.flow} texel-neighbour-same={same:.3f} "
           f"{ms:.4f} ms/launch (incl. margin kernel)  {nbytes / ms / 1e6:.0f} GB/s  checksum={float(tw.sum()):.6e}")
 
 
