@@ -612,8 +612,12 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     for (int i = 0; i < 12; i++) accP[i] = accW[i] = 0.0f;
     const uint32_t xmax = (uint32_t)(2 * dimX - 5), ymax = (uint32_t)(2 * dimY - 5);
     uint32_t safeBits = 0;  // bit n: frame n took the fast path
-#pragma unroll
+    // one frame after the other in a real loop (not unrolled: the two bodies would only compete for
+    // registers); the frame's pointers are picked with scalar selects so the argument struct stays
+    // in SGPRs
+#pragma unroll 1
     for (int n = 0; n < NF; n++) {
+        const uint16_t* raw = (NF > 1 && n) ? fr.f[NF - 1].raw : fr.f[0].raw;
         float2 Ft[2][3];
 #pragma unroll
         for (int r = 0; r < 2; r++)
@@ -642,14 +646,11 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
                 const float* p = (const float*)&sM[n][mr][lx + cell];
                 return p[ch];
             };
-            const uint16_t* raw = fr.f[n].raw;
             strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
             strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
             strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
             strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
         }
-        // one frame after the other: interleaving the two bodies only costs registers
-        __builtin_amdgcn_sched_barrier(0);
     }
     float* myP = (float*)&sAcc[ly][0][0] + lx * 12;  // this lane's 4 pixels x 3 channels inside the staged segment
     float* myW = (float*)&sAcc[ly][1][0] + lx * 12;
@@ -665,8 +666,9 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
             ((float4*)myW)[j] = c;
         }
     }
-#pragma unroll
+#pragma unroll 1
     for (int n = 0; n < NF; n++) {
+        const TileFrame& F = (NF > 1 && n) ? fr.f[NF - 1] : fr.f[0];
         if (!((safeBits >> n) & 1u) && stripLive) {
             // border / wild-flow / non-PSD strips: the straight per-pixel arithmetic on the staged values
 #pragma unroll 1
@@ -675,8 +677,8 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
                 if (X >= 1 && X < hrW - 1) {
                     pix3 px = {myP[3 * k], myP[3 * k + 1], myP[3 * k + 2]};
                     pix3 tw = {myW[3 * k], myW[3 * k + 1], myW[3 * k + 2]};
-                    accumulate_pixel_core<GEOM_FULL, true>(X, Y, fr.f[n].raw, fr.f[n].mask, kernelParam, fr.f[n].shifts, glv,
-                                                           dimX, dimY, 2, strideMask, cfaPacked, px, tw);
+                    accumulate_pixel_core<GEOM_FULL, true>(X, Y, F.raw, F.mask, kernelParam, F.shifts, glv, dimX, dimY, 2,
+                                                           strideMask, cfaPacked, px, tw);
                     myP[3 * k] = px.x; myP[3 * k + 1] = px.y; myP[3 * k + 2] = px.z;
                     myW[3 * k] = tw.x; myW[3 * k + 1] = tw.y; myW[3 * k + 2] = tw.z;
                 }
