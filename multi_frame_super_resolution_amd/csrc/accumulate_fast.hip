@@ -464,13 +464,13 @@ __global__ void __launch_bounds__(256)
 //    arithmetic), are updated in LDS and written back in memory order: every accumulator access
 //    on the HBM side is a fully used 128-byte line.
 #define TILE_COLS 66
-// waves per SIMD the register budget is sized for: 3 (one frame, 168 VGPRs, no spills; measured
-// faster than 4 waves with spills) and 2 (two frames per launch)
+// waves per SIMD the register budget is sized for: 4 with one frame per launch (125 VGPRs), 3 with two
+// (168 VGPRs, 4 spilled; 128 would spill 67)
 #ifndef TILE_WAVES
-#define TILE_WAVES 3
+#define TILE_WAVES 4
 #endif
 #ifndef TILE_WAVES2
-#define TILE_WAVES2 2
+#define TILE_WAVES2 3
 #endif
 #define TILE_WAVES_NF(NF) ((NF) == 1 ? TILE_WAVES : TILE_WAVES2)
 // NF frames per launch (1 or 2).  Everything that does not depend on the frame is done once for
@@ -640,6 +640,12 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
         }
         if (safe) {
             safeBits |= 1u << n;
+            // The 4 x 13 tap weights depend on the kernel parameters only, so the compiler would keep
+            // them in registers for the second frame (214 VGPRs, 2 waves per SIMD).  Recomputing them per
+            // frame (+10 % instructions) fits 168 VGPRs = 3 waves per SIMD and is 9 % faster (0.724 ->
+            // 0.660 ms per pair, profiles/r01_ab_pair_nohoist.txt): occupancy beats instruction count here.
+#pragma unroll
+            for (int k = 0; k < 4; k++) asm volatile("" : "+v"(kxa[k]), "+v"(kya[k]), "+v"(kza[k]));
             // certainty: LDS row of the mask row that tap row jt reads = ((ly + jt - 2) >> 2) + 1; column lx + cell
             auto mval = [&](int jt, int cell, int ch) {
                 const int mr = ((ly + jt - 2) >> 2) + 1;
