@@ -250,6 +250,8 @@ int mfsr_resampleFloat3(const mfsr_float3* in, int inPitch, int inW, int inH, mf
 int mfsr_quantize(const mfsr_float3* in, int inPitch, uint16_t* out16, uint8_t* out8, int width, int height,
                   float maxOut, mfsr_stream_t stream);
 int mfsr_fill_f32(float* dst, size_t count, float value, mfsr_stream_t stream);
+/* one-pixel border ring of a float4 image := 0: what ComputeRobustnessMask (:37) leaves unwritten */
+int mfsr_zeroRing_f32x4(mfsr_float4* img, int pitch, int width, int height, mfsr_stream_t stream);
 /* variant selector of the accumulate kernels (tests, A/B benchmarks):
  * 0 = straight kernel, exp(-w/2) with the ocml expf (tight parity against the oracle);
  * 1 = straight kernel, v_exp_f32; 2 (default) = additionally the restructured x2
@@ -272,10 +274,12 @@ int mfsr_tileSquaredSums(const float* refImg, float* outValues, int imgWidth, in
                          int tileSize, int tileCountX, int tileCountY, mfsr_stream_t stream);
 /* D2+D3+D4 for one Lucas-Kanade iteration in one launch (LDS-tiled warp,
  * derivative and separable window sums).  Flow is double-buffered: shiftsOut
- * must not alias shiftsIn (tile halos read neighbouring tiles' flow). */
+ * must not alias shiftsIn (tile halos read neighbouring tiles' flow).  outScale
+ * multiplies the flow written (1 = plain iteration; the last iteration of a
+ * pipeline passes its tracking->raw pixel factor instead of a mfsr_scaleFlow pass). */
 int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_float2* shiftsOut, int pitchShift,
                                    const float* refImg, const float* movedImg, int pitchImg, int width, int height,
-                                   int halfWindowSize, float minDet, mfsr_stream_t stream);
+                                   int halfWindowSize, float minDet, float outScale, mfsr_stream_t stream);
 /* E1+E2 (derivatives + structure tensor) in one launch */
 int mfsr_structureTensorFused(const float* img, int imgPitch, mfsr_float3* outImg, int outPitch, int width, int height,
                               mfsr_stream_t stream);

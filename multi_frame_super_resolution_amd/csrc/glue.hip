@@ -387,6 +387,38 @@ __global__ void __launch_bounds__(256) k_fill(float* __restrict__ dst, size_t co
     for (; i < count; i += stride) dst[i] = value;
 }
 
+// one-pixel border ring of a float4 image := 0 (ComputeRobustnessMask never writes it)
+__global__ void __launch_bounds__(256) k_zeroRing4(float4* __restrict__ img, int pitch, int width, int height)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = 2 * width + 2 * height;
+    if (i >= n) return;
+    int x, y;
+    if (i < width) {
+        x = i;
+        y = 0;
+    } else if (i < 2 * width) {
+        x = i - width;
+        y = height - 1;
+    } else if (i < 2 * width + height) {
+        x = 0;
+        y = i - 2 * width;
+    } else {
+        x = width - 1;
+        y = i - 2 * width - height;
+    }
+    row_ptr(img, pitch, y)[x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+extern "C" int mfsr_zeroRing_f32x4(mfsr_float4* img, int pitch, int width, int height, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(img && width > 0 && height > 0 && (long long)pitch >= 16LL * width && (pitch & 15) == 0 &&
+                 ((uintptr_t)img & 15) == 0);
+    hipLaunchKernelGGL(k_zeroRing4, dim3(mfsr_cdiv(2 * width + 2 * height, 256)), dim3(256), 0, mfsr_s(stream), (float4*)img,
+                       pitch, width, height);
+    return mfsr_launch_status("zeroRing_f32x4");
+}
+
 extern "C" int mfsr_fill_f32(float* dst, size_t count, float value, mfsr_stream_t stream)
 {
     MFSR_REQUIRE(dst != nullptr);

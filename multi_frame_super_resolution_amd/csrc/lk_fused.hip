@@ -51,7 +51,7 @@ template <int HT, int LK_TX>
 __global__ void __launch_bounds__(LK_TX * LK_TY)
     k_lkIterationFused(const float2* __restrict__ shiftsIn, float2* __restrict__ shiftsOut, int pitchShift,
                        const float* __restrict__ refImg, const float* __restrict__ movedImg, int pitchImg, int width,
-                       int height, int hRuntime, float minDet)
+                       int height, int hRuntime, float minDet, float outScale)
 {
     constexpr int LK_THREADS = LK_TX * LK_TY;
     const int h = HT > 0 ? HT : hRuntime;
@@ -207,6 +207,10 @@ __global__ void __launch_bounds__(LK_TX * LK_TY)
                 shift.y += UV1;
             }
         }
+        // outScale != 1 on the last iteration of a pipeline whose tracking image is smaller than the raw
+        // frame: the flow leaves in raw-pixel units without a separate scaling pass (x1 is exact)
+        shift.x *= outScale;
+        shift.y *= outScale;
         row_ptr(shiftsOut, pitchShift, pxY)[pxX] = shift;
     };
     {
@@ -229,7 +233,7 @@ __global__ void __launch_bounds__(LK_TX * LK_TY)
 
 extern "C" int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_float2* shiftsOut, int pitchShift,
                                               const float* refImg, const float* movedImg, int pitchImg, int width,
-                                              int height, int halfWindowSize, float minDet, mfsr_stream_t stream)
+                                              int height, int halfWindowSize, float minDet, float outScale, mfsr_stream_t stream)
 {
     MFSR_REQUIRE(shiftsIn && shiftsOut && shiftsIn != shiftsOut && refImg && movedImg && width > 0 && height > 0);
     MFSR_REQUIRE(halfWindowSize >= 0 && halfWindowSize <= 15);
@@ -254,7 +258,8 @@ extern "C" int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_
             }                                                                                                          \
         }                                                                                                              \
         hipLaunchKernelGGL((k_lkIterationFused<HT, TXV>), grid, block, lds, mfsr_s(stream), (const float2*)shiftsIn,   \
-                           (float2*)shiftsOut, pitchShift, refImg, movedImg, pitchImg, width, height, h, minDet);      \
+                           (float2*)shiftsOut, pitchShift, refImg, movedImg, pitchImg, width, height, h, minDet,       \
+                           outScale);                                                                                 \
     } while (0)
 #define LK_CASE(HT)                                                                                                    \
     case HT:                                                                                                           \

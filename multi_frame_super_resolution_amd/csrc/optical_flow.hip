@@ -37,13 +37,19 @@ __global__ void __launch_bounds__(256)
     const int pxX = blockIdx.x * blockDim.x + threadIdx.x;
     const int pxY = blockIdx.y * blockDim.y + threadIdx.y;
     if (pxX >= imgWidth || pxY >= imgHeight) return;
+    // cosf(0) = 1 and sinf(0) = 0 exactly: the (uniform) zero-rotation case skips the two libm expansions
+    float cf = 1.0f, sf = 0.0f;
+    if (baseRotation != 0.0f) {
+        cf = cosf(baseRotation);
+        sf = sinf(baseRotation);
+    }
     float2 shift;
-    shift.x = cosf(baseRotation) * -baseShift.x - sinf(baseRotation) * -baseShift.y;
-    shift.y = sinf(baseRotation) * -baseShift.x + cosf(baseRotation) * -baseShift.y;
+    shift.x = cf * -baseShift.x - sf * -baseShift.y;
+    shift.y = sf * -baseShift.x + cf * -baseShift.y;
     const float patchCenterX = (float)(pxX - imgWidth / 2);
     const float patchCenterY = (float)(pxY - imgHeight / 2);
-    shift.x += cosf(baseRotation) * patchCenterX - sinf(baseRotation) * patchCenterY - patchCenterX;
-    shift.y += sinf(baseRotation) * patchCenterX + cosf(baseRotation) * patchCenterY - patchCenterY;
+    shift.x += cf * patchCenterX - sf * patchCenterY - patchCenterX;
+    shift.y += sf * patchCenterX + cf * patchCenterY - patchCenterY;
     const float2 shiftPatch =
         tex2<ADDR_CLAMP>(texShift, ((float)pxX + 0.5f) / (float)imgWidth, ((float)pxY + 0.5f) / (float)imgHeight);
     shift.x += shiftPatch.x;

@@ -560,7 +560,8 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
             if (c.fused) {
                 TRY(mfsr_lucasKanadeIterationFused((const mfsr_float2*)flow->ptr, (mfsr_float2*)other->ptr, flow->pitch,
                                                    (const float*)L.refPyr[0].ptr, (const float*)L.movPyr[0].ptr,
-                                                   L.refPyr[0].pitch, L.tw, L.th, c.lkHalfWindow, c.lkMinDet, stream));
+                                                   L.refPyr[0].pitch, L.tw, L.th, c.lkHalfWindow, c.lkMinDet,
+                                                   it == c.lkIterations - 1 ? (float)L.flowScale : 1.0f, stream));
                 Img* t = flow;
                 flow = other;
                 other = t;
@@ -577,10 +578,10 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
                                           c.lkMinDet, stream));
             }
         }
-        if (L.flowScale != 1)
+        if (L.flowScale != 1 && !(c.fused && c.lkIterations > 0))  // the fused LK scales on its last iteration
             TRY(mfsr_scaleFlow((mfsr_float2*)flow->ptr, flow->pitch, L.tw, L.th, (float)L.flowScale, stream));
-        // F: robustness mask (1-px ring is never written by the kernel -> pre-zero)
-        MFSR_HIP_TRY(hipMemsetAsync(mask->ptr, 0, (size_t)mask->pitch * mask->h, mfsr_s(stream)));
+        // F: robustness mask (the 1-px ring is never written by the kernel -> zero it)
+        TRY(mfsr_zeroRing_f32x4((mfsr_float4*)mask->ptr, mask->pitch, L.hw, L.hh, stream));
         TRY(mfsr_ComputeRobustnessMask((const mfsr_float3*)L.refHalf.ptr, (const mfsr_float3*)L.movHalf.ptr,
                                        (mfsr_float4*)mask->ptr, as_tex(*flow), L.hw, L.hh, L.refHalf.pitch, mask->pitch,
                                        c.alpha, c.beta, c.thresholdM, stream));

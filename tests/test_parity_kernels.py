@@ -705,7 +705,13 @@ def test_lucasKanadeIterationFused_equals_chain(orc, hip):
     orc.call("ComputeDerivativesKernel", W, H, pitch_of(Ix), Ix, Iy, Iz, Tex(warped), Tex(ref))  # source = warped
     orc.call("lucasKanadeOptim", flow, Ix, Iy, Iz, pitch_of(flow), pitch_of(Ix), W, H, hw, 1e-4)
     out = np.full((H, W, 2), 99, np.float32)
-    hip.call("lucasKanadeIterationFused", flow0, out, pitch_of(out), ref, mov, pitch_of(ref), W, H, hw, 1e-4)
+    hip.call("lucasKanadeIterationFused", flow0, out, pitch_of(out), ref, mov, pitch_of(ref), W, H, hw, 1e-4, 1.0)
+    # outScale folds the pipeline's mfsr_scaleFlow pass into the last iteration: same bits
+    out2 = np.full((H, W, 2), 99, np.float32)
+    hip.call("lucasKanadeIterationFused", flow0, out2, pitch_of(out2), ref, mov, pitch_of(ref), W, H, hw, 1e-4, 2.0)
+    scaled = out.copy()
+    hip.call("scaleFlow", scaled, pitch_of(scaled), W, H, 2.0)
+    assert_bitexact(scaled, out2, "lucasKanadeIterationFused(outScale)")
     # separable window sums + M^-1 * sum(grad*It) instead of sum(M^-1 grad * It): rounding only
     np.testing.assert_allclose(out, flow, atol=1e-4)
     assert np.abs(flow - flow0).max() > 0.05   # the iteration did move the flow
