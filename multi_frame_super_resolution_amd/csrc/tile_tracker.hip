@@ -687,6 +687,8 @@ extern "C" int mfsr_fftshift(mfsr_float2* fft, int width, int height, mfsr_strea
 //    NSX multiply-adds but leaves about one wavefront per SIMD at 4K (every candidate is one serial
 //    chain of T*T multiply-adds, so tiles x candidates is all the parallelism there is): measured
 //    36.6 us (NSX = 1), 59 us (2), 60 us (3) per launch, so NSX = 1 is the default (MFSR_TRK_NSX).
+//    (Reading the template through the scalar cache instead of LDS -- its address is wave-uniform with
+//    one tile per workgroup -- was also tried: 41 us, the SMEM and LDS waits share one counter.)
 // One wavefront per tile then reduces D with shuffles and lane 0 runs the quadratic fit.
 #define TRK_THREADS 128
 template <int TRK_NSX>
