@@ -324,7 +324,9 @@ typedef struct {
     int32_t applyGamma;
     int32_t fused;           /* 1: fused MI355X kernels; 0: one launch per reference kernel */
     int32_t pairFrames;      /* 1: add_frame fuses frames two at a time (see mfsr_burst_add_frame) */
-    int32_t reserved[6];
+    int32_t asyncFuse;       /* 1: the warp+fuse launches run on a stream owned by the burst, concurrently with the
+                                alignment of the following frames on the caller's stream (see mfsr_burst_add_frame) */
+    int32_t reserved[5];
 } mfsr_config;
 
 typedef struct mfsr_burst mfsr_burst;
@@ -347,10 +349,15 @@ int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, mfsr_stream_
  * both are fused in one pass over the accumulators (half the accumulator traffic): after an
  * odd number of calls one frame is still waiting -- its raw buffer must stay untouched and the
  * accumulators do not contain it -- until the next add_frame, mfsr_burst_flush, finish or
- * finish_rows has been issued on the stream. */
+ * finish_rows has been issued on the stream.
+ * With cfg.asyncFuse the warp+fuse launches go to a high-priority stream the burst owns (ordered by
+ * events after the alignment on the caller's stream), so the fuse of frames k, k+1 overlaps the
+ * alignment of k+2, k+3.  The caller's stream sees the accumulators complete only after
+ * mfsr_burst_flush / finish / finish_rows / set_reference (they join the two streams), and every raw
+ * buffer handed to add_frame must stay untouched until one of those has been issued. */
 int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float3* imgOut,
                          mfsr_float3* totalWeights, mfsr_stream_t stream);
-/* fuse a frame that is still waiting for its partner (no-op otherwise) */
+/* fuse a frame that is still waiting for its partner and make the caller's stream wait for every fuse issued so far */
 int mfsr_burst_flush(mfsr_burst* b, mfsr_stream_t stream);
 /* ApplyWeighting (+fallback) + optional gamma; outImg float3 HR (may be NULL),
  * out16 dense interleaved u16 HR (may be NULL). */

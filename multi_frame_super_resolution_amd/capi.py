@@ -58,7 +58,7 @@ class Config(ctypes.Structure):
         ("Dth", ctypes.c_float), ("Dtr", ctypes.c_float), ("kDetail", ctypes.c_float), ("kDenoise", ctypes.c_float),
         ("kStretch", ctypes.c_float), ("kShrink", ctypes.c_float),
         ("weightThreshold", ctypes.c_float), ("applyGamma", ctypes.c_int32), ("fused", ctypes.c_int32),
-        ("pairFrames", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6),
+        ("pairFrames", ctypes.c_int32), ("asyncFuse", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5),
     ]
 
 

@@ -33,6 +33,10 @@ namespace {
 
 constexpr int kMaxLevels = 4;
 constexpr int kMaxTimedLaunches = 4096;
+// Per-frame products (flow, certainty mask) live in a ring of kRing slots: a frame's slot stays
+// untouched until the warp+fuse that consumes it has run, which with cfg.asyncFuse happens on the
+// burst's own stream while the caller's stream already aligns the next frames.
+constexpr int kRing = 4;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -56,8 +60,8 @@ struct Layout {
     Img tensor, tensorTmp, tensorSm;         // float3, tracking res
     Img fallback;                            // float3, W x H
     Img tmpA, tmpB;                          // float, tracking res
-    Img flowBuf[3];                          // float2, tracking res: two for the LK ping-pong + the flow of a frame waiting for its pair
-    Img maskBuf[2];                          // float4, half res (current frame / frame waiting for its pair)
+    Img flowBuf[2 * kRing];                  // float2, tracking res: per ring slot the two buffers of the LK ping-pong
+    Img maskBuf[kRing];                      // float4, half res, one per ring slot
     Img shifts[kMaxLevels], pre[kMaxLevels]; // float2, tile grids
     // unfused path scratch
     Img warped, Ix, Iy, It, rawf;
@@ -143,8 +147,8 @@ void make_layout(const mfsr_config* c, char* base, Layout* L)
     L->fallback = b.image(L->W, L->H, 12);
     L->tmpA = b.image(L->tw, L->th, 4);
     L->tmpB = b.image(L->tw, L->th, 4);
-    for (int i = 0; i < 3; i++) L->flowBuf[i] = b.image(L->tw, L->th, 8);
-    for (int i = 0; i < 2; i++) L->maskBuf[i] = b.image(L->hw, L->hh, 16);
+    for (int i = 0; i < 2 * kRing; i++) L->flowBuf[i] = b.image(L->tw, L->th, 8);
+    for (int i = 0; i < kRing; i++) L->maskBuf[i] = b.image(L->hw, L->hh, 16);
     size_t maxTileFloats = 0, maxTiles = 0, maxDist = 0;
     for (int l = 0; l < c->levels; l++) {
         const int f = c->levelFactor[l];
@@ -207,12 +211,19 @@ struct mfsr_burst {
     // both are fused in one pass over the accumulators; flush/finish fuses a frame left alone
     struct Pending {
         bool has;
+        int slot;
         const uint16_t* raw;
         Img* flow;
         Img* mask;
         mfsr_float3 *imgOut, *totalWeights;
     } pend;
     int nFramesTimed;
+    // ring + asynchronous fuse (cfg.asyncFuse)
+    int frameCounter;
+    hipStream_t fuseStream;             // high priority, non-blocking; null without asyncFuse
+    hipEvent_t evAligned[kRing];        // recorded on the caller's stream when slot's flow/mask are complete
+    hipEvent_t evFused[kRing];          // recorded on fuseStream when the fuse that read the slot is done
+    bool fusedOutstanding[kRing];       // evFused[slot] recorded and not yet waited for by the caller's stream
     // optional per-launch timing of the accumulate kernel (bench.py roofline leg)
     bool timing;
     int nEvents;
@@ -278,6 +289,7 @@ extern "C" int mfsr_config_default(mfsr_config* cfg, int width, int height, int 
     cfg->applyGamma = 0;
     cfg->fused = 1;
     cfg->pairFrames = 1;
+    cfg->asyncFuse = 0;  // +5 % burst throughput, -17 % on the fuse launches it overlaps: opt-in
     return MFSR_OK;
 }
 
@@ -319,11 +331,30 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     b->maskCur = &b->L.maskBuf[0];
     b->pend.has = false;
     b->nFramesTimed = 0;
-    b->haveRef = false;
     b->timing = false;
     b->nEvents = 0;
     memset(b->evStart, 0, sizeof(b->evStart));
     memset(b->evStop, 0, sizeof(b->evStop));
+    b->frameCounter = 0;
+    b->fuseStream = nullptr;
+    for (int i = 0; i < kRing; i++) {
+        b->evAligned[i] = b->evFused[i] = nullptr;
+        b->fusedOutstanding[i] = false;
+    }
+    if (cfg->asyncFuse) {
+        int lo = 0, hi = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->fuseStream, hipStreamNonBlocking, hi);
+        for (int i = 0; i < kRing && e == hipSuccess; i++) {
+            e = hipEventCreateWithFlags(&b->evAligned[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evFused[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) {
+            mfsr_burst_destroy(b);
+            return MFSR_E_NODEVICE;
+        }
+    }
+    b->haveRef = false;
     *out = b;
     return MFSR_OK;
 }
@@ -335,6 +366,12 @@ extern "C" void mfsr_burst_destroy(mfsr_burst* b)
         if (b->evStart[i]) (void)hipEventDestroy(b->evStart[i]);
         if (b->evStop[i]) (void)hipEventDestroy(b->evStop[i]);
     }
+    if (b->fuseStream) (void)hipStreamSynchronize(b->fuseStream);
+    for (int i = 0; i < kRing; i++) {
+        if (b->evAligned[i]) (void)hipEventDestroy(b->evAligned[i]);
+        if (b->evFused[i]) (void)hipEventDestroy(b->evFused[i]);
+    }
+    if (b->fuseStream) (void)hipStreamDestroy(b->fuseStream);
     delete b;
 }
 
@@ -485,11 +522,19 @@ static int track_tiles(mfsr_burst* b, mfsr_stream_t stream)
 }
 
 // G: one or two aligned frames onto the caller's accumulators (timed with HIP events on request)
-static int accumulate_frames(mfsr_burst* b, int n, const uint16_t* raw0, const uint16_t* raw1, Img* flow0, Img* flow1,
-                             Img* mask0, Img* mask1, mfsr_float3* imgOut, mfsr_float3* totalWeights, mfsr_stream_t stream)
+static int accumulate_frames(mfsr_burst* b, int n, int slot0, int slot1, const uint16_t* raw0, const uint16_t* raw1,
+                             Img* flow0, Img* flow1, Img* mask0, Img* mask1, mfsr_float3* imgOut,
+                             mfsr_float3* totalWeights, mfsr_stream_t callerStream)
 {
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
+    // with asyncFuse the launch goes to the burst's own stream, ordered after the alignment of its frames
+    mfsr_stream_t stream = callerStream;
+    if (b->fuseStream) {
+        stream = (mfsr_stream_t)b->fuseStream;
+        MFSR_HIP_TRY(hipStreamWaitEvent(b->fuseStream, b->evAligned[slot0], 0));
+        if (n == 2) MFSR_HIP_TRY(hipStreamWaitEvent(b->fuseStream, b->evAligned[slot1], 0));
+    }
     const mfsr_float3 white = {c.white[0], c.white[1], c.white[2]};
     const mfsr_float3 black = {c.black[0], c.black[1], c.black[2]};
     const int strideOut = 12 * L.hrW;
@@ -513,15 +558,39 @@ static int accumulate_frames(mfsr_burst* b, int n, const uint16_t* raw0, const u
         b->nEvents++;
         b->nFramesTimed += n;
     }
+    if (b->fuseStream) {
+        MFSR_HIP_TRY(hipEventRecord(b->evFused[slot0], b->fuseStream));
+        b->fusedOutstanding[slot0] = true;
+        if (n == 2) {
+            MFSR_HIP_TRY(hipEventRecord(b->evFused[slot1], b->fuseStream));
+            b->fusedOutstanding[slot1] = true;
+        }
+    }
     return MFSR_OK;
 }
 
+// the caller's stream waits for every fuse issued so far (no-op without asyncFuse)
+static int join_fuse(mfsr_burst* b, mfsr_stream_t stream)
+{
+    if (!b->fuseStream) return MFSR_OK;
+    for (int i = 0; i < kRing; i++)
+        if (b->fusedOutstanding[i]) {
+            MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evFused[i], 0));
+            b->fusedOutstanding[i] = false;
+        }
+    return MFSR_OK;
+}
+
+// fuse a frame still waiting for its partner, then join: afterwards the caller's stream sees every frame
 static int flush_pending(mfsr_burst* b, mfsr_stream_t stream)
 {
-    if (!b->pend.has) return MFSR_OK;
-    mfsr_burst::Pending p = b->pend;
-    b->pend.has = false;
-    return accumulate_frames(b, 1, p.raw, nullptr, p.flow, nullptr, p.mask, nullptr, p.imgOut, p.totalWeights, stream);
+    if (b->pend.has) {
+        mfsr_burst::Pending p = b->pend;
+        b->pend.has = false;
+        TRY(accumulate_frames(b, 1, p.slot, -1, p.raw, nullptr, p.flow, nullptr, p.mask, nullptr, p.imgOut, p.totalWeights,
+                              stream));
+    }
+    return join_fuse(b, stream);
 }
 
 extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float3* imgOut,
@@ -533,18 +602,15 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
     Layout& L = b->L;
     TRY(mfsr_set_cfa_pattern(c.cfa));
 
-    // buffers of this frame: the two flow buffers and the mask buffer a waiting frame does not hold
-    Img* flow = nullptr;
-    Img* other = nullptr;
-    for (int i = 0; i < 3; i++) {
-        Img* f = &L.flowBuf[i];
-        if (b->pend.has && f == b->pend.flow) continue;
-        if (!flow)
-            flow = f;
-        else if (!other)
-            other = f;
+    // ring slot of this frame; its buffers are free once the fuse that read them last has run
+    const int slot = b->frameCounter++ % kRing;
+    if (b->fuseStream && b->fusedOutstanding[slot]) {
+        MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evFused[slot], 0));
+        b->fusedOutstanding[slot] = false;
     }
-    Img* mask = (b->pend.has && b->pend.mask == &L.maskBuf[0]) ? &L.maskBuf[1] : &L.maskBuf[0];
+    Img* flow = &L.flowBuf[2 * slot];
+    Img* other = &L.flowBuf[2 * slot + 1];
+    Img* mask = &L.maskBuf[slot];
     if (isReference) {
         // identity flow, certainty 1
         MFSR_HIP_TRY(hipMemsetAsync(flow->ptr, 0, (size_t)flow->pitch * flow->h, mfsr_s(stream)));
@@ -588,15 +654,17 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
     }
     b->flowCur = flow;
     b->maskCur = mask;
+    if (b->fuseStream) MFSR_HIP_TRY(hipEventRecord(b->evAligned[slot], mfsr_s(stream)));
     // G: accumulate onto the HR grid -- alone, or together with the frame that was waiting for a partner
     if (b->pend.has && (b->pend.imgOut != imgOut || b->pend.totalWeights != totalWeights)) TRY(flush_pending(b, stream));
     if (b->pend.has) {
         mfsr_burst::Pending p = b->pend;
         b->pend.has = false;
-        return accumulate_frames(b, 2, p.raw, raw, p.flow, flow, p.mask, mask, imgOut, totalWeights, stream);
+        return accumulate_frames(b, 2, p.slot, slot, p.raw, raw, p.flow, flow, p.mask, mask, imgOut, totalWeights, stream);
     }
     if (c.pairFrames) {
         b->pend.has = true;
+        b->pend.slot = slot;
         b->pend.raw = raw;
         b->pend.flow = flow;
         b->pend.mask = mask;
@@ -604,7 +672,7 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
         b->pend.totalWeights = totalWeights;
         return MFSR_OK;
     }
-    return accumulate_frames(b, 1, raw, nullptr, flow, nullptr, mask, nullptr, imgOut, totalWeights, stream);
+    return accumulate_frames(b, 1, slot, -1, raw, nullptr, flow, nullptr, mask, nullptr, imgOut, totalWeights, stream);
 }
 
 extern "C" int mfsr_burst_flush(mfsr_burst* b, mfsr_stream_t stream)
