@@ -94,6 +94,7 @@ def main():
                     help="N>1: run the RCCL exchange of burst i on the compute stream instead of overlapping it with the "
                          "align+fuse of burst i+1")
     ap.add_argument("--force-pipelined", action="store_true", help="use the two-context pipelined step loop even at N=1 (test)")
+    ap.add_argument("--no-pair", action="store_true", help="cfg.pairFrames = 0: one warp+fuse launch per frame (the reference's structure)")
     ap.add_argument("--async-fuse", action="store_true",
                     help="cfg.asyncFuse: warp+fuse on the burst's own stream, overlapping the alignment of the next frames "
                          "(+5 % burst throughput, the fuse launches themselves get 17 % slower; off by default)")
@@ -130,6 +131,8 @@ def main():
     n_frames = fpg if args.strong else fpg * world
     cfg = default_config(W, H, n_frames, s, mono)
     cfg.fused = 0 if args.unfused else 1
+    if args.no_pair:
+        cfg.pairFrames = 0
     if args.async_fuse and not args.h2d:   # (the upload ring of --h2d reuses a raw buffer right after the next add_frame)
         cfg.asyncFuse = 1
     pipe = BurstPipeline(cfg, dev)

@@ -86,6 +86,104 @@ __device__ __forceinline__ float selm(uint32_t m, float a, float b)  // m == ~0u
     return __uint_as_float(__builtin_amdgcn_bitop3_b32(m, __float_as_uint(a), __float_as_uint(b), 0xCA));
 }
 
+// certainty of the colour under an even (Ee) / odd (Eo) site column of a tap row, from the three channel
+// certainties m[] of a mask cell.  mya: lane mask "the site row has absolute y parity 1"; mP: "site
+// column 0 has absolute x parity 1".
+template <int CFA>
+__device__ __forceinline__ void resolve_certainty(uint32_t mya, uint32_t mP, const float (&m)[3], float& Ee, float& Eo)
+{
+    constexpr bool mono = Cfa<CFA>::count(MFSR_GREEN) == 4;
+    if (mono) {
+        Ee = Eo = m[MFSR_GREEN];
+    } else if (Cfa<CFA>::col(0, 1) == Cfa<CFA>::col(1, 0)) {
+        // Bayer, G on the anti-diagonal (RGGB, BGGR): the colour on the diagonal is picked by the y
+        // parity alone; even site columns see it when x parity == y parity, else they see G
+        const float X = selm(mya, m[Cfa<CFA>::col(1, 1)], m[Cfa<CFA>::col(0, 0)]);
+        const uint32_t d = mya ^ mP;  // x parity != y parity
+        Ee = selm(d, m[Cfa<CFA>::col(0, 1)], X);
+        Eo = selm(d, X, m[Cfa<CFA>::col(0, 1)]);
+    } else if (Cfa<CFA>::col(0, 0) == Cfa<CFA>::col(1, 1)) {
+        // Bayer, G on the diagonal (GRBG, GBRG)
+        const float X = selm(mya, m[Cfa<CFA>::col(1, 0)], m[Cfa<CFA>::col(0, 1)]);
+        const uint32_t d = mya ^ mP;
+        Ee = selm(d, X, m[Cfa<CFA>::col(0, 0)]);
+        Eo = selm(d, m[Cfa<CFA>::col(0, 0)], X);
+    } else {
+        const float cA = selm(mya, m[Cfa<CFA>::col(1, 0)], m[Cfa<CFA>::col(0, 0)]);  // absolute x parity 0
+        const float cB = selm(mya, m[Cfa<CFA>::col(1, 1)], m[Cfa<CFA>::col(0, 1)]);  // absolute x parity 1
+        Ee = selm(mP, cB, cA);
+        Eo = selm(mP, cA, cB);
+    }
+}
+
+// relative CFA-position class sums (class (yc, xc) sits at CFA position (yc ^ Q, xc ^ P)) -> R, G, B,
+// normalised and added to pixel K of the strip
+template <int K, int CFA>
+__device__ __forceinline__ void classes_to_channels(const float (&S)[2][2], const float (&W)[2][2], uint32_t mP, uint32_t mQ,
+                                                    const StripLevels& lv, float* accP, float* accW)
+{
+    constexpr bool mono = Cfa<CFA>::count(MFSR_GREEN) == 4;
+    auto at_pos = [&](const float(&T)[2][2], int yp, int xp) {
+        const float q0 = selm(mP, T[yp][xp ^ 1], T[yp][xp]);          // Q == 0
+        const float q1 = selm(mP, T[yp ^ 1][xp ^ 1], T[yp ^ 1][xp]);  // Q == 1
+        return selm(mQ, q1, q0);
+    };
+    float chS[3] = {0, 0, 0}, chW[3] = {0, 0, 0};
+    const float totS = (S[0][0] + S[0][1]) + (S[1][0] + S[1][1]);
+    const float totW = (W[0][0] + W[0][1]) + (W[1][0] + W[1][1]);
+    if (mono) {
+        chS[1] = totS;
+        chW[1] = totW;
+    } else {
+        constexpr int pr = Cfa<CFA>::pos_of(MFSR_RED), pb = Cfa<CFA>::pos_of(MFSR_BLUE);
+        if ((pr ^ pb) == 3) {
+            // red and blue on opposite corners of the 2x2 cell (every Bayer pattern): they are the two
+            // classes of one diagonal; which diagonal follows from P ^ Q, which end from Q
+            const uint32_t dq = ((pr >> 1) ^ (pr & 1)) ? ~(mP ^ mQ) : (mP ^ mQ);  // all ones: the anti-diagonal classes
+            const uint32_t mR = (pr >> 1) ? ~mQ : mQ;                            // all ones: red is the class in row 1
+            const float s0 = selm(dq, S[0][1], S[0][0]), s1 = selm(dq, S[1][0], S[1][1]);
+            const float w0 = selm(dq, W[0][1], W[0][0]), w1 = selm(dq, W[1][0], W[1][1]);
+            chS[0] = selm(mR, s1, s0);
+            chS[2] = selm(mR, s0, s1);
+            chW[0] = selm(mR, w1, w0);
+            chW[2] = selm(mR, w0, w1);
+        } else {
+            chS[0] = at_pos(S, pr >> 1, pr & 1);
+            chW[0] = at_pos(W, pr >> 1, pr & 1);
+            chS[2] = at_pos(S, pb >> 1, pb & 1);
+            chW[2] = at_pos(W, pb >> 1, pb & 1);
+        }
+        // weights are in [0,1] on this path (PSD kernel parameters), so the two green positions can be
+        // taken as total - red - blue without cancellation trouble
+        chS[1] = (totS - chS[0]) - chS[2];
+        chW[1] = (totW - chW[0]) - chW[2];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        accP[3 * K + c] += (chS[c] - lv.black[c] * chW[c]) * lv.invWhite[c];
+        accW[3 * K + c] += chW[c];
+    }
+}
+
+// the 13 unique tap weights of a pixel: n = jt*5+it, w[n] == w[24-n]; exponents pre-scaled by
+// -0.5*log2(e) and built from sums (2 adds per weight)
+__device__ __forceinline__ void tap_weights13(float kx, float ky, float kz, float (&w)[13])
+{
+    const float a1 = kx * -0.72134752044448170368f, b1 = ky * -0.72134752044448170368f;
+    const float c1 = kz * -0.72134752044448170368f;
+    const float A[3] = {0.0f, a1, 4.0f * a1}, B[3] = {0.0f, b1, 4.0f * b1};
+#pragma unroll
+    for (int n = 0; n < 12; n++) {
+        const int py = n / 5 - 2, px = n % 5 - 2;
+        const int apx = px < 0 ? -px : px, apy = py < 0 ? -py : py;
+        const float d = apx == 0 ? B[apy] : (apy == 0 ? A[apx] : A[apx] + B[apy]);
+        // the caller admits only positive semi-definite kernel parameters, so every exponent is <= 0 and
+        // every weight in [0, 1]: the non-finite rule of :429-430 cannot fire
+        w[n] = __builtin_amdgcn_exp2f(px * py == 0 ? d : d + (float)(2 * px * py) * c1);
+    }
+    w[12] = 1.0f;
+}
+
 // Second formulation of the same pixel: the dynamic part (which raw site a tap lands on) is
 // applied to the WEIGHTS, not to the values.
 //  * site sums: out = sum_sites raw[j][i] * Om[j][i], Om[j][i] = sum of w*certainty over the taps on
@@ -108,7 +206,6 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
     const uint32_t mbx = 0u - (uint32_t)(qx & 1), mby = 0u - (uint32_t)(qy & 1);
     const uint32_t nbx = ~mbx, nby = ~mby;
     const uint32_t mP = 0u - (uint32_t)(x0 & 1), mQ = 0u - (uint32_t)(y0 & 1);
-    constexpr bool mono = Cfa<CFA>::count(MFSR_GREEN) == 4;
     auto andm = [](uint32_t m, float a) { return __uint_as_float(m & __float_as_uint(a)); };
 
     float s[3][3];
@@ -120,21 +217,8 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
             for (int i = 0; i < 3; i++) s[j][i] = (float)r[j * dimX + i];
     }
 
-    // 13 unique weights, n = jt*5+it, w[n] == w[24-n]; exponents pre-scaled by -0.5*log2(e)
     float w[13];
-    {
-        const float a1 = kx * -0.72134752044448170368f, b1 = ky * -0.72134752044448170368f;
-        const float c1 = kz * -0.72134752044448170368f;
-        const float A[3] = {0.0f, a1, 4.0f * a1}, B[3] = {0.0f, b1, 4.0f * b1};
-#pragma unroll
-        for (int n = 0; n < 12; n++) {
-            const int py = n / 5 - 2, px = n % 5 - 2;
-            const int apx = px < 0 ? -px : px, apy = py < 0 ? -py : py;
-            const float d = apx == 0 ? B[apy] : (apy == 0 ? A[apx] : A[apx] + B[apy]);
-            w[n] = __builtin_amdgcn_exp2f(px * py == 0 ? d : d + (float)(2 * px * py) * c1);
-        }
-        w[12] = 1.0f;
-    }
+    tap_weights13(kx, ky, kz, w);
     // tap columns 1 and 3: part that joins the lower / the upper site column
     float wl[13], wh[13];
 #pragma unroll
@@ -168,27 +252,7 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
             float m[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) m[ch] = mval(jt, cellLo + c, ch);
-            if (mono) {
-                Ee[c] = Eo[c] = m[MFSR_GREEN];
-            } else if (Cfa<CFA>::col(0, 1) == Cfa<CFA>::col(1, 0)) {
-                // Bayer, G on the anti-diagonal (RGGB, BGGR): the colour on the diagonal is picked by the y
-                // parity alone; even site columns see it when x parity == y parity, else they see G
-                const float X = selm(mya, m[Cfa<CFA>::col(1, 1)], m[Cfa<CFA>::col(0, 0)]);
-                const uint32_t d = mya ^ mP;  // x parity != y parity
-                Ee[c] = selm(d, m[Cfa<CFA>::col(0, 1)], X);
-                Eo[c] = selm(d, X, m[Cfa<CFA>::col(0, 1)]);
-            } else if (Cfa<CFA>::col(0, 0) == Cfa<CFA>::col(1, 1)) {
-                // Bayer, G on the diagonal (GRBG, GBRG)
-                const float X = selm(mya, m[Cfa<CFA>::col(1, 0)], m[Cfa<CFA>::col(0, 1)]);
-                const uint32_t d = mya ^ mP;
-                Ee[c] = selm(d, X, m[Cfa<CFA>::col(0, 0)]);
-                Eo[c] = selm(d, m[Cfa<CFA>::col(0, 0)], X);
-            } else {
-                const float cA = selm(mya, m[Cfa<CFA>::col(1, 0)], m[Cfa<CFA>::col(0, 0)]);  // absolute x parity 0
-                const float cB = selm(mya, m[Cfa<CFA>::col(1, 1)], m[Cfa<CFA>::col(0, 1)]);  // absolute x parity 1
-                Ee[c] = selm(mP, cB, cA);
-                Eo[c] = selm(mP, cA, cB);
-            }
+            resolve_certainty<CFA>(mya, mP, m, Ee[c], Eo[c]);
         }
         // site column 0: tap 0, tap 1 if bx == 0
         C[jt][0] = cidx(0) == cidx(1) ? (W_(jt, 0) + WL(jt, 1)) * Ee[cidx(0)]
@@ -229,44 +293,7 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
     S[1][1] = s[1][1] * Om[1][1];
     W[1][1] = Om[1][1];
 
-    auto at_pos = [&](const float(&T)[2][2], int yp, int xp) {
-        const float q0 = selm(mP, T[yp][xp ^ 1], T[yp][xp]);          // Q == 0
-        const float q1 = selm(mP, T[yp ^ 1][xp ^ 1], T[yp ^ 1][xp]);  // Q == 1
-        return selm(mQ, q1, q0);
-    };
-    float chS[3] = {0, 0, 0}, chW[3] = {0, 0, 0};
-    const float totS = (S[0][0] + S[0][1]) + (S[1][0] + S[1][1]);
-    const float totW = (W[0][0] + W[0][1]) + (W[1][0] + W[1][1]);
-    if (mono) {
-        chS[1] = totS;
-        chW[1] = totW;
-    } else {
-        constexpr int pr = Cfa<CFA>::pos_of(MFSR_RED), pb = Cfa<CFA>::pos_of(MFSR_BLUE);
-        if ((pr ^ pb) == 3) {
-            // red and blue on opposite corners of the 2x2 cell (every Bayer pattern): they are the two
-            // classes of one diagonal; which diagonal follows from P ^ Q, which end from Q
-            const uint32_t dq = ((pr >> 1) ^ (pr & 1)) ? ~(mP ^ mQ) : (mP ^ mQ);  // all ones: the anti-diagonal classes
-            const uint32_t mR = (pr >> 1) ? ~mQ : mQ;                            // all ones: red is the class in row 1
-            const float s0 = selm(dq, S[0][1], S[0][0]), s1 = selm(dq, S[1][0], S[1][1]);
-            const float w0 = selm(dq, W[0][1], W[0][0]), w1 = selm(dq, W[1][0], W[1][1]);
-            chS[0] = selm(mR, s1, s0);
-            chS[2] = selm(mR, s0, s1);
-            chW[0] = selm(mR, w1, w0);
-            chW[2] = selm(mR, w0, w1);
-        } else {
-            chS[0] = at_pos(S, pr >> 1, pr & 1);
-            chW[0] = at_pos(W, pr >> 1, pr & 1);
-            chS[2] = at_pos(S, pb >> 1, pb & 1);
-            chW[2] = at_pos(W, pb >> 1, pb & 1);
-        }
-        chS[1] = (totS - chS[0]) - chS[2];
-        chW[1] = (totW - chW[0]) - chW[2];
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        accP[3 * K + c] += (chS[c] - lv.black[c] * chW[c]) * lv.invWhite[c];
-        accW[3 * K + c] += chW[c];
-    }
+    classes_to_channels<K, CFA>(S, W, mP, mQ, lv, accP, accW);
 }
 
 // Frame margin (HR pixels) that the strip/tile kernels leave to k_accumulateMargin: taps of
