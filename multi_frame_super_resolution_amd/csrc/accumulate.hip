@@ -109,6 +109,12 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
                                        mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
                                        mfsr_stream_t stream);  // accumulate_fast.hip
 
+int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
+                                      mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
+                                      mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
+                                      mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
+                                      mfsr_stream_t stream);  // accumulate_fast.hip
+
 static int check_superres_args(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
                                const mfsr_float4* certaintyMask, const mfsr_tex2d& kernelParam, const mfsr_tex2d& shifts,
                                int dimX, int dimY, int outW, int strideOut, int strideMask)
@@ -157,6 +163,10 @@ extern "C" int mfsr_accumulateSuperResFull(const uint16_t* dataIn, mfsr_float3* 
         mfsr_try_launch_accumulate2x_strip(1, &dataIn, imgOut, totalWeights, &certaintyMask, kernelParam, &shifts, whiteLevel,
                                            blackLevel, dimX, dimY, strideOut, strideMask, stream) == 1)
         return mfsr_launch_status("accumulateSuperResFull(strip)");
+    if (g_accumulate_fast == 2 && scale == 4 &&
+        mfsr_try_launch_accumulate4x_tile(1, &dataIn, imgOut, totalWeights, &certaintyMask, kernelParam, &shifts, whiteLevel,
+                                          blackLevel, dimX, dimY, strideOut, strideMask, stream) == 1)
+        return mfsr_launch_status("accumulateSuperResFull(x4 tile)");
     dim3 block(64, 4), grid(mfsr_cdiv((long long)dimX * scale, 64), mfsr_cdiv((long long)dimY * scale, 4));
     const Levels3 lv = make_levels(whiteLevel, blackLevel);
     if (g_accumulate_fast)
@@ -195,6 +205,10 @@ extern "C" int mfsr_accumulateSuperResFull2(const uint16_t* dataIn0, const uint1
         mfsr_try_launch_accumulate2x_strip(2, raws, imgOut, totalWeights, masks, kernelParam, sh, whiteLevel, blackLevel, dimX,
                                            dimY, strideOut, strideMask, stream) == 1)
         return mfsr_launch_status("accumulateSuperResFull2(strip)");
+    if (g_accumulate_fast == 2 && scale == 4 &&
+        mfsr_try_launch_accumulate4x_tile(2, raws, imgOut, totalWeights, masks, kernelParam, sh, whiteLevel, blackLevel, dimX,
+                                          dimY, strideOut, strideMask, stream) == 1)
+        return mfsr_launch_status("accumulateSuperResFull2(x4 tile)");
     rc = mfsr_accumulateSuperResFull(dataIn0, imgOut, totalWeights, certaintyMask0, kernelParam, shifts0, whiteLevel, blackLevel,
                                      dimX, dimY, scale, strideOut, strideMask, stream);
     if (rc) return rc;

@@ -305,9 +305,9 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
 __global__ void __launch_bounds__(256)
     k_accumulateMargin(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
                        const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
-                       int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
+                       int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int scale)
 {
-    const int hrW = 2 * dimX, hrH = 2 * dimY, M = STRIP_MARGIN;
+    const int hrW = scale * dimX, hrH = scale * dimY, M = STRIP_MARGIN;
     const int rowLen = hrW - 2;                    // x in [1, hrW-1)
     const int nTop = (M - 1) * rowLen;             // y in [1, M)
     const int nBot = (M - 1) * rowLen;             // y in [hrH-M, hrH-1)
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256)
         return;
     }
     accumulate_pixel_generic<GEOM_FULL, true>(x, y, raw, imgOut, totalWeights, certaintyMask, kernelParam, shifts, glv, dimX,
-                                              dimY, 2, strideOut, strideMask, cfaPacked);
+                                              dimY, scale, strideOut, strideMask, cfaPacked);
 }
 
 // FR = HR pixels per field texel along each axis (4: fields at LR/2, the Bayer
@@ -743,6 +743,307 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     }
 }
 
+// ---- x4 ------------------------------------------------------------------------------------------
+// The same pixel at scale 4.  The 5x5 HR taps of a pixel fall on 2x2 raw sites: tap column `it` lands
+// on site column (ph + it) >> 2 with ph = (X + sx - 2) & 3, i.e. on column 1 iff ph + it >= 4 -- a lane
+// mask per tap column (none for it = 0, all for it = 4), applied to the weights as in strip_pixel.
+// Each site is its own CFA-position class (relative to the parity of (x0, y0)).  K8 = X & 7 is the
+// pixel's position in its certainty cell (8 HR pixels at scale 4), K8 & 3 its position in the strip.
+template <int K8, int CFA, typename MaskF>
+__device__ __forceinline__ void strip_pixel4(int X, int Y, int sx, int sy, float kx, float ky, float kz,
+                                              const uint16_t* __restrict__ raw, int dimX, MaskF mval,
+                                              const StripLevels& lv, float* accP, float* accW)
+{
+    const int qx = X + sx - 2, qy = Y + sy - 2;
+    const int x0 = qx >> 2, y0 = qy >> 2;
+    const uint32_t bx0 = 0u - (uint32_t)(qx & 1), bx1 = 0u - (uint32_t)((qx >> 1) & 1);
+    const uint32_t by0 = 0u - (uint32_t)(qy & 1), by1 = 0u - (uint32_t)((qy >> 1) & 1);
+    // mx[it]: tap column it lands on site column 1 (ph + it >= 4); same for rows
+    const uint32_t mx[5] = {0u, bx0 & bx1, bx1, bx0 | bx1, ~0u};
+    const uint32_t my[5] = {0u, by0 & by1, by1, by0 | by1, ~0u};
+    const uint32_t mP = 0u - (uint32_t)(x0 & 1), mQ = 0u - (uint32_t)(y0 & 1);
+    auto andm = [](uint32_t m, float a) { return __uint_as_float(m & __float_as_uint(a)); };
+
+    float s[2][2];
+    {
+        const uint16_t* r = raw + (size_t)y0 * dimX + x0;
+        s[0][0] = (float)r[0];
+        s[0][1] = (float)r[1];
+        s[1][0] = (float)r[dimX];
+        s[1][1] = (float)r[dimX + 1];
+    }
+    float w[13];
+    tap_weights13(kx, ky, kz, w);
+    auto W_ = [&](int jt, int it) { const int n = jt * 5 + it; return w[n <= 12 ? n : 24 - n]; };
+
+    // certainty cell column of tap column it, relative to the cell left of the strip's own: 0..2
+    auto cellOf = [](int it) { return (K8 + it - 2 + 8) >> 3; };
+    constexpr int cellLo = (K8 - 2 + 8) >> 3;
+    constexpr bool twoCells = ((K8 + 4 - 2 + 8) >> 3) != cellLo;
+
+    float C[5][2];  // per tap row: w * certainty summed per site column
+#pragma unroll
+    for (int jt = 0; jt < 5; jt++) {
+        const uint32_t mya = mQ ^ my[jt];  // absolute y parity of the site row this tap row lands on
+        float Ee[2], Eo[2];
+#pragma unroll
+        for (int c = 0; c < (twoCells ? 2 : 1); c++) {
+            float m[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) m[ch] = mval(jt, cellLo + c, ch);
+            resolve_certainty<CFA>(mya, mP, m, Ee[c], Eo[c]);
+        }
+        // weights per (site column, cell), then one multiply with the certainty of that pair
+        float lo[2] = {0.0f, 0.0f}, hi[2] = {0.0f, 0.0f};
+        bool loUsed[2] = {false, false}, hiUsed[2] = {false, false};
+#pragma unroll
+        for (int it = 0; it < 5; it++) {
+            const int c = cellOf(it) - cellLo;
+            const float wt = W_(jt, it);
+            if (it < 4) {
+                const float v = it == 0 ? wt : andm(~mx[it], wt);
+                lo[c] = loUsed[c] ? lo[c] + v : v;
+                loUsed[c] = true;
+            }
+            if (it > 0) {
+                const float v = it == 4 ? wt : andm(mx[it], wt);
+                hi[c] = hiUsed[c] ? hi[c] + v : v;
+                hiUsed[c] = true;
+            }
+        }
+        float c0 = loUsed[0] ? lo[0] * Ee[0] : 0.0f;
+        if (twoCells && loUsed[1]) c0 = loUsed[0] ? __builtin_fmaf(lo[1], Ee[1], c0) : lo[1] * Ee[1];
+        float c1 = hiUsed[0] ? hi[0] * Eo[0] : 0.0f;
+        if (twoCells && hiUsed[1]) c1 = hiUsed[0] ? __builtin_fmaf(hi[1], Eo[1], c1) : hi[1] * Eo[1];
+        C[jt][0] = c0;
+        C[jt][1] = c1;
+    }
+    float S[2][2], W[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float o0 = ((C[0][i] + andm(~my[1], C[1][i])) + andm(~my[2], C[2][i])) + andm(~my[3], C[3][i]);
+        const float o1 = ((andm(my[1], C[1][i]) + andm(my[2], C[2][i])) + andm(my[3], C[3][i])) + C[4][i];
+        W[0][i] = o0;
+        W[1][i] = o1;
+        S[0][i] = s[0][i] * o0;
+        S[1][i] = s[1][i] * o1;
+    }
+    classes_to_channels<(K8 & 3), CFA>(S, W, mP, mQ, lv, accP, accW);
+}
+
+// x4 LDS tile kernel (fields at HR/8: the Bayer pipeline at scale 4).  One 64x4 workgroup covers a
+// 512 x 2 HR tile: wave (r, h) = (threadIdx.y >> 1, threadIdx.y & 1) owns row r and the strips whose
+// position in the 8-pixel certainty cell is h (lane lx -> strip 2*lx + h), so K8 is a compile-time
+// constant per wave.  Staging as in the x2 kernel (64 + 2 field texels x 3 rows, column/row fractions,
+// accumulator rows through LDS-DMA); the two waves of a row share its staged segment, hence the
+// workgroup barriers around the LDS update.
+template <int CFA, int NF>
+__global__ void __launch_bounds__(256, 3)
+    k_accumulate4xTile(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
+                       Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked,
+                       int tilesX)
+{
+    const int bIdY = (int)blockIdx.x / tilesX, bIdX = (int)blockIdx.x - bIdY * tilesX;
+    const int hrW = 4 * dimX, hrH = 4 * dimY;
+    const int Y0 = 2 * bIdY;
+    if (Y0 < STRIP_MARGIN || Y0 >= hrH - STRIP_MARGIN) return;  // whole workgroup (margin rows)
+    __shared__ float4 sK[3][TILE_COLS];  // .w = 1 if the texel is PSD and finite, else 0
+    __shared__ float2 sF[NF][3][TILE_COLS];
+    __shared__ float4 sM[NF][3][TILE_COLS];
+    __shared__ __attribute__((aligned(16))) float sColA[512];
+    __shared__ float sRowB[2];
+    __shared__ __attribute__((aligned(16))) float4 sAcc[2][2][384];  // [row][plane-set][6 KiB row segment]
+    const int lx = threadIdx.x, ly = threadIdx.y;
+    const int r = ly >> 1, h = ly & 1;
+    const int X0 = bIdX * 512 + 8 * lx + 4 * h;
+    const int Y = Y0 + r;
+    const int fw = kernelParam.width, fh = kernelParam.height;  // == hrW/8, hrH/8 (checked on the host)
+    const int mw = dimX / 2, mh = dimY / 2;
+    const int band = Y0 >> 3;  // field / certainty row of the tile
+    {
+        const int t = ly * 64 + lx;
+        if (t < 3 * TILE_COLS) {
+            const int rr = t / TILE_COLS, c = t - rr * TILE_COLS;
+            const int gy = band - 1 + rr, gx = bIdX * 64 - 1 + c;
+            const int fy = clampi(gy, 0, fh - 1), fx = clampi(gx, 0, fw - 1);
+            float4 k = row_ptr((const float4*)kernelParam.ptr, kernelParam.pitch, fy)[fx];
+            k.w = psd_ok(k.x, k.y, k.z) ? 1.0f : 0.0f;
+            sK[rr][c] = k;
+#pragma unroll
+            for (int n = 0; n < NF; n++) {
+                sF[n][rr][c] = row_ptr((const float2*)fr.f[n].shifts.ptr, fr.f[n].shifts.pitch, fy)[fx];
+                const float4 m = row_ptr(fr.f[n].mask, strideMask, clampi(gy, 0, mh - 1))[clampi(gx, 0, mw - 1)];
+                sM[n][rr][c] = make_float4(sane(m.x), sane(m.y), sane(m.z), 0.0f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            // column of the tile: the float path of tex_coord, texel column predicted and verified
+            const int cl = t + 256 * u, X = bIdX * 512 + cl;
+            const float posX = ((float)X + 0.5f) / (float)hrW;
+            float xB = posX * (float)fw - 0.5f;
+            if (!finitef(xB)) xB = 0.0f;
+            const float fxf = floorf(xB);
+            const int c8 = X >> 3, ci = (X & 7) < 4 ? 0 : 1;
+            const bool ok = (f2i(fxf) == c8 - 1 + ci) && (c8 + ci <= fw - 1);
+            sColA[cl] = ok ? xB - fxf : -1.0f;
+        }
+        if (t < 2) {
+            const int Yr = Y0 + t;
+            const float posY = ((float)Yr + 0.5f) / (float)hrH;
+            float yB = posY * (float)fh - 0.5f;
+            if (!finitef(yB)) yB = 0.0f;
+            const float fyf = floorf(yB);
+            const int frr = (Yr & 7) < 4 ? 0 : 1;
+            const bool ok = (f2i(fyf) == band - 1 + frr) && f2i(fyf) >= 0 && f2i(fyf) + 1 <= fh - 1;
+            sRowB[t] = ok ? yB - fyf : -1.0f;
+        }
+    }
+    // accumulator rows of the tile -> LDS (wave (r, h) brings half h of row r), asynchronously
+    const size_t rowBytes = (size_t)hrW * 12;
+    const size_t segByte = (size_t)bIdX * 6144 + (size_t)h * 3072;
+    char* gP = (char*)imgOut + (size_t)Y * strideOut + segByte;
+    char* gW = (char*)totalWeights + (size_t)Y * strideOut + segByte;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const size_t off = (size_t)(j * 64 + lx) * 16;
+        if (segByte + off + 16 <= rowBytes) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gP + off),
+                                             (__attribute__((address_space(3))) void*)&sAcc[r][0][h * 192 + j * 64], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW + off),
+                                             (__attribute__((address_space(3))) void*)&sAcc[r][1][h * 192 + j * 64], 16, 0, 0);
+        }
+    }
+    __syncthreads();
+    const bool stripLive = X0 >= STRIP_MARGIN && X0 < hrW - STRIP_MARGIN;
+
+    const int fr_ = (Y0 & 7) < 4 ? 0 : 1;
+    const float b = sRowB[r];
+    const float4 av4 = ((const float4*)sColA)[2 * lx + h];
+    const float av[4] = {av4.x, av4.y, av4.z, av4.w};
+    const bool geomOk = stripLive && b >= 0.0f && fminf(fminf(av[0], av[1]), fminf(av[2], av[3])) >= 0.0f;
+    const int cb = lx + h;  // LDS column of the left texel of this strip's texel pair
+
+    float kxa[4], kya[4], kza[4];
+    bool kOk;
+    {
+        float4 Kt[2][2];
+#pragma unroll
+        for (int r2 = 0; r2 < 2; r2++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) Kt[r2][c] = sK[fr_ + r2][cb + c];
+        kOk = (Kt[0][0].w * Kt[0][1].w) * (Kt[1][0].w * Kt[1][1].w) > 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float w00 = (1.0f - av[k]) * (1.0f - b), w10 = av[k] * (1.0f - b), w01 = (1.0f - av[k]) * b, w11 = av[k] * b;
+            auto mix = [&](float t00, float t10, float t01, float t11) {
+                return __builtin_fmaf(w11, t11, __builtin_fmaf(w01, t01, __builtin_fmaf(w10, t10, w00 * t00)));
+            };
+            kxa[k] = mix(Kt[0][0].x, Kt[0][1].x, Kt[1][0].x, Kt[1][1].x);
+            kya[k] = mix(Kt[0][0].y, Kt[0][1].y, Kt[1][0].y, Kt[1][1].y);
+            kza[k] = mix(Kt[0][0].z, Kt[0][1].z, Kt[1][0].z, Kt[1][1].z);
+        }
+    }
+
+    float accP[12], accW[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) accP[i] = accW[i] = 0.0f;
+    const uint32_t xmax = (uint32_t)(4 * dimX - 5), ymax = (uint32_t)(4 * dimY - 5);
+    const int yq = Y & 7;
+    uint32_t safeBits = 0;
+#pragma unroll 1
+    for (int n = 0; n < NF; n++) {
+        const uint16_t* raw = (NF > 1 && n) ? fr.f[NF - 1].raw : fr.f[0].raw;
+        float avn[4] = {av[0], av[1], av[2], av[3]};
+        float bn = b;
+#pragma unroll
+        for (int k = 0; k < 4; k++) asm volatile("" : "+v"(avn[k]));
+        asm volatile("" : "+v"(bn));
+        float2 Ft[2][2];
+#pragma unroll
+        for (int r2 = 0; r2 < 2; r2++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) Ft[r2][c] = sF[n][fr_ + r2][cb + c];
+        int sx[4], sy[4];
+        bool safe = geomOk && kOk;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float ux = lerp4(Ft[0][0].x, Ft[0][1].x, Ft[1][0].x, Ft[1][1].x, avn[k], bn);
+            const float uy = lerp4(Ft[0][0].y, Ft[0][1].y, Ft[1][0].y, Ft[1][1].y, avn[k], bn);
+            sx[k] = round2i(ux * 4.0f);
+            sy[k] = round2i(uy * 4.0f);
+            const int qx = X0 + k + sx[k] - 2, qy = Y + sy[k] - 2;
+            safe = safe && (uint32_t)(sx[k] + (1 << 20)) < (2u << 20) && (uint32_t)(sy[k] + (1 << 20)) < (2u << 20) &&
+                   (uint32_t)qx <= xmax && (uint32_t)qy <= ymax;
+        }
+        if (safe) {
+            safeBits |= 1u << n;
+#pragma unroll
+            for (int k = 0; k < 4; k++) asm volatile("" : "+v"(kxa[k]), "+v"(kya[k]), "+v"(kza[k]));
+            // certainty: LDS row of the mask row that tap row jt reads, column lx + cell
+            auto mval = [&](int jt, int cell, int ch) {
+                const int mr = ((yq + jt - 2 + 8) >> 3);
+                const float* p = (const float*)&sM[n][mr][lx + cell];
+                return p[ch];
+            };
+            if (h == 0) {
+                strip_pixel4<0, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<1, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<2, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<3, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
+            } else {
+                strip_pixel4<4, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<5, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<6, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<7, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
+            }
+        }
+    }
+    // every wave's part of the staged rows must have landed before any lane updates them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* myP = (float*)&sAcc[r][0][0] + (2 * lx + h) * 12;
+    float* myW = (float*)&sAcc[r][1][0] + (2 * lx + h) * 12;
+    if (safeBits) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float4 a = ((float4*)myP)[j], c = ((float4*)myW)[j];
+            a.x += accP[4 * j + 0]; a.y += accP[4 * j + 1]; a.z += accP[4 * j + 2]; a.w += accP[4 * j + 3];
+            c.x += accW[4 * j + 0]; c.y += accW[4 * j + 1]; c.z += accW[4 * j + 2]; c.w += accW[4 * j + 3];
+            ((float4*)myP)[j] = a;
+            ((float4*)myW)[j] = c;
+        }
+    }
+#pragma unroll 1
+    for (int n = 0; n < NF; n++) {
+        const TileFrame& F = (NF > 1 && n) ? fr.f[NF - 1] : fr.f[0];
+        if (!((safeBits >> n) & 1u) && stripLive) {
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+                const int X = X0 + k;
+                if (X >= 1 && X < hrW - 1) {
+                    pix3 px = {myP[3 * k], myP[3 * k + 1], myP[3 * k + 2]};
+                    pix3 tw = {myW[3 * k], myW[3 * k + 1], myW[3 * k + 2]};
+                    accumulate_pixel_core<GEOM_FULL, true>(X, Y, F.raw, F.mask, kernelParam, F.shifts, glv, dimX, dimY, 4,
+                                                           strideMask, cfaPacked, px, tw);
+                    myP[3 * k] = px.x; myP[3 * k + 1] = px.y; myP[3 * k + 2] = px.z;
+                    myW[3 * k] = tw.x; myW[3 * k + 1] = tw.y; myW[3 * k + 2] = tw.z;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // write the half-row segments back in memory order
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const size_t off = (size_t)(j * 64 + lx) * 16;
+        if (segByte + off + 16 <= rowBytes) {
+            *(float4*)(gP + off) = sAcc[r][0][h * 192 + j * 64 + lx];
+            *(float4*)(gW + off) = sAcc[r][1][h * 192 + j * 64 + lx];
+        }
+    }
+}
+
 constexpr int pack_cfa(int c00, int c01, int c10, int c11) { return c00 | (c01 << 2) | (c10 << 4) | (c11 << 6); }
 
 int g_strip_xcd_remap = 0;  // MFSR_XCD_REMAP=1: XCD-aware tile order (measured: no gain)
@@ -845,7 +1146,7 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
         const int M = STRIP_MARGIN;
         const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
         hipLaunchKernelGGL(k_accumulateMargin, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, st, dataIn[n], pI, pT,
-                           (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp);
+                           (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp, 2);
     };
 #define STRIP_CASE(a, b, c, d)                                                                                         \
     case pack_cfa(a, b, c, d):                                                                                         \
@@ -877,5 +1178,83 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
         default: break;
     }
 #undef STRIP_CASE
+    return 0;
+}
+
+// x4: returns 1 if the x4 tile kernel took the nFrames (1 or 2) frames, 0 if the geometry is not its
+// (fields at HR/8, even dimensions); the caller then uses the straight kernel.
+int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
+                                      mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
+                                      mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
+                                      mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
+                                      mfsr_stream_t stream)
+{
+    read_env_once();
+    if (nFrames < 1 || nFrames > 2 || !g_strip_use_tile) return 0;
+    int cfa[4];
+    mfsr_get_cfa_pattern(cfa);
+    for (int i = 0; i < 4; i++)
+        if (cfa[i] > MFSR_BLUE) return 0;
+    const int packed2 = pack_cfa(cfa[0], cfa[1], cfa[2], cfa[3]);
+    const int hrW = 4 * dimX, hrH = 4 * dimY;
+    if ((dimX & 1) || (dimY & 1) || ((uintptr_t)imgOut & 15) || ((uintptr_t)totalWeights & 15) || (strideOut & 15)) return 0;
+    if (hrW < 4 * STRIP_MARGIN || hrH < 4 * STRIP_MARGIN) return 0;
+    for (int n = 0; n < nFrames; n++)
+        if (!(kernelParam.width == shifts[n].width && kernelParam.height == shifts[n].height && kernelParam.width * 8 == hrW &&
+              kernelParam.height * 8 == hrH && kernelParam.width >= 4))
+            return 0;
+    Levels3 glv;
+    StripLevels lv;
+    const float wl[3] = {whiteLevel.x, whiteLevel.y, whiteLevel.z}, bl[3] = {blackLevel.x, blackLevel.y, blackLevel.z};
+    for (int c = 0; c < 3; c++) {
+        glv.white[c] = wl[c];
+        glv.black[c] = bl[c];
+        lv.black[c] = bl[c];
+        lv.invWhite[c] = 1.0f / wl[c];
+    }
+    hipStream_t st = mfsr_s(stream);
+    pix3* pI = (pix3*)imgOut;
+    pix3* pT = (pix3*)totalWeights;
+    const int cp = mfsr_cfa_packed();
+    const int tilesX = mfsr_cdiv(hrW, 512), tilesY = hrH / 2;
+    const dim3 block(64, 4), grid(tilesX * tilesY);
+    auto launch_margin = [&](int n) {
+        const int M = STRIP_MARGIN;
+        const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
+        hipLaunchKernelGGL(k_accumulateMargin, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, st, dataIn[n], pI, pT,
+                           (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp, 4);
+    };
+#define X4_CASE(a, b, c, d)                                                                                            \
+    case pack_cfa(a, b, c, d):                                                                                         \
+        if (nFrames == 2) {                                                                                            \
+            TileFrames<2> fr;                                                                                          \
+            for (int n = 0; n < 2; n++) {                                                                              \
+                fr.f[n].raw = dataIn[n];                                                                               \
+                fr.f[n].mask = (const float4*)certaintyMask[n];                                                        \
+                fr.f[n].shifts = shifts[n];                                                                            \
+            }                                                                                                          \
+            hipLaunchKernelGGL((k_accumulate4xTile<pack_cfa(a, b, c, d), 2>), grid, block, 0, st, fr, pI, pT, kernelParam, \
+                               glv, lv, dimX, dimY, strideOut, strideMask, cp, tilesX);                                \
+            launch_margin(0);                                                                                          \
+            launch_margin(1);                                                                                          \
+        } else {                                                                                                       \
+            TileFrames<1> fr;                                                                                          \
+            fr.f[0].raw = dataIn[0];                                                                                   \
+            fr.f[0].mask = (const float4*)certaintyMask[0];                                                            \
+            fr.f[0].shifts = shifts[0];                                                                                \
+            hipLaunchKernelGGL((k_accumulate4xTile<pack_cfa(a, b, c, d), 1>), grid, block, 0, st, fr, pI, pT, kernelParam, \
+                               glv, lv, dimX, dimY, strideOut, strideMask, cp, tilesX);                                \
+            launch_margin(0);                                                                                          \
+        }                                                                                                              \
+        return 1;
+    switch (packed2) {
+        X4_CASE(MFSR_RED, MFSR_GREEN, MFSR_GREEN, MFSR_BLUE)   // RGGB
+        X4_CASE(MFSR_BLUE, MFSR_GREEN, MFSR_GREEN, MFSR_RED)   // BGGR
+        X4_CASE(MFSR_GREEN, MFSR_RED, MFSR_BLUE, MFSR_GREEN)   // GRBG
+        X4_CASE(MFSR_GREEN, MFSR_BLUE, MFSR_RED, MFSR_GREEN)   // GBRG
+        X4_CASE(MFSR_GREEN, MFSR_GREEN, MFSR_GREEN, MFSR_GREEN) // monochrome
+        default: break;
+    }
+#undef X4_CASE
     return 0;
 }

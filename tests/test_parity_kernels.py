@@ -241,6 +241,53 @@ def test_accumulate_x2_two_frames_per_call(orc, hip, pat, field):
     assert np.abs(hw_).max() > 0.5
 
 
+@pytest.mark.parametrize("pair", [False, True])
+@pytest.mark.parametrize("pat", ["RGGB", "GRBG", "MONO"])
+def test_accumulate_x4_tile_kernel(orc, hip, pat, pair):
+    """x4 tile kernel (fields at HR/8) against the oracle, one and two frames per call: smooth flows so
+    that most strips take the fast path, a wild patch, a NaN flow texel, NaN certainties, hostile
+    kernel parameters; odd tile counts (width not a multiple of 512 HR pixels)."""
+    W, H, s = 168, 72, 4
+    cfa = [1, 1, 1, 1] if pat == "MONO" else PATTERNS[pat]
+    orc.set_cfa(cfa)
+    hip.set_cfa(cfa)
+    white, black = F3([3839, 3700, 3900]), F3([256, 260, 250])
+    fh, fw = H // 2, W // 2
+
+    def make():
+        raw0, imgOut, tw, mask0 = _accum_inputs(130, W, H, W * s, H * s, nan_frac=0.01)
+        raw1, _, _, mask1 = _accum_inputs(131, W, H, W * s, H * s, nan_frac=0.01)
+        kp = _kernel_field(132, fh, fw, 4)
+        yy, xx = np.mgrid[0:fh, 0:fw].astype(np.float32)
+        sh0 = np.stack([1.3 + 0.01 * xx, -2.2 + 0.02 * yy], -1).astype(np.float32)
+        sh1 = np.stack([-2.6 - 0.015 * yy, 0.4 + 0.01 * xx], -1).astype(np.float32)
+        sh0[10:14, 10:14] = 1e9
+        sh1[20, 20] = np.nan
+        return raw0, raw1, imgOut, tw, mask0, mask1, kp, sh0, sh1
+
+    raw0, raw1, oi, ow, m0, m1, kp, sh0, sh1 = make()
+    todo = ((raw0, m0, sh0), (raw1, m1, sh1)) if pair else ((raw0, m0, sh0),)
+    for raw, m, sh in todo:
+        orc.call("accumulateSuperResFull", raw, oi, ow, m, Tex(kp), Tex(sh), white, black, W, H, s, pitch_of(oi), pitch_of(m))
+    raw0, raw1, hi, hw_, m0, m1, kp, sh0, sh1 = make()
+    if pair:
+        hip.call("accumulateSuperResFull2", raw0, raw1, hi, hw_, m0, m1, Tex(kp), Tex(sh0), Tex(sh1), white, black, W, H, s,
+                 pitch_of(hi), pitch_of(m0))
+    else:
+        hip.call("accumulateSuperResFull", raw0, hi, hw_, m0, Tex(kp), Tex(sh0), white, black, W, H, s, pitch_of(hi),
+                 pitch_of(m0))
+    np.testing.assert_allclose(hi, oi, rtol=3e-5, atol=3e-5)
+    np.testing.assert_allclose(hw_, ow, rtol=3e-5, atol=3e-5)
+    # the straight kernel on the same inputs: the tile kernel really ran (sums are re-associated)
+    if not pair:
+        hip.L.set_accumulate_fast_exp(1)
+        raw0, raw1, si, sw, m0, m1, kp, sh0, sh1 = make()
+        hip.call("accumulateSuperResFull", raw0, si, sw, m0, Tex(kp), Tex(sh0), white, black, W, H, s, pitch_of(si), pitch_of(m0))
+        hip.L.set_accumulate_fast_exp(2)
+        np.testing.assert_allclose(hi, si, rtol=1e-5, atol=1e-5)
+        assert not np.array_equal(hi, si) or pat == "MONO"
+
+
 def test_accumulateImages_x1(orc, hip):
     W, H = 64, 40
     orc.set_cfa(RGGB)
