@@ -166,7 +166,9 @@ __device__ __forceinline__ void classes_to_channels(const float (&S)[2][2], cons
 }
 
 // the 13 unique tap weights of a pixel: n = jt*5+it, w[n] == w[24-n]; exponents pre-scaled by
-// -0.5*log2(e) and built from sums (2 adds per weight)
+// -0.5*log2(e) and built from sums (2 adds per weight).  (Building ten of the twelve from products of
+// four exponentials -- six v_exp_f32 instead of twelve -- was measured: no gain, 0.642 vs 0.636 ms per
+// pair, and it needs a bound on |kz|; the twelve exponentials stay.)
 __device__ __forceinline__ void tap_weights13(float kx, float ky, float kz, float (&w)[13])
 {
     const float a1 = kx * -0.72134752044448170368f, b1 = ky * -0.72134752044448170368f;

@@ -241,6 +241,41 @@ def test_accumulate_x2_two_frames_per_call(orc, hip, pat, field):
     assert np.abs(hw_).max() > 0.5
 
 
+@pytest.mark.parametrize("s", [2, 4])
+def test_accumulate_anisotropic_kernels(orc, hip, s):
+    """Kernel parameters as ComputeKernelParam makes them at strong edges: inverse covariances with
+    eigenvalues 0.7 .. 44 at every orientation (|kz| up to ~22), plus a patch of extreme ones
+    (|kz| up to 150): tap weights spanning many orders of magnitude."""
+    W, H = 192, 96
+    orc.set_cfa(RGGB)
+    hip.set_cfa(RGGB)
+    white, black = F3([3839, 3700, 3900]), F3([256, 260, 250])
+    fh, fw = H // 2, W // 2
+    r = rng(140)
+    th = r.uniform(0, np.pi, (fh, fw))
+    l1 = r.uniform(0.7, 2.7, (fh, fw))
+    l2 = 0.7 + 43.0 * r.uniform(0, 1, (fh, fw)) ** 2
+    l2[5:9, 5:9] = 300.0             # |kz| up to 150
+    c, sn = np.cos(th), np.sin(th)
+    kp = np.zeros((fh, fw, 4), np.float32)
+    kp[..., 0] = l1 * c * c + l2 * sn * sn
+    kp[..., 1] = l1 * sn * sn + l2 * c * c
+    kp[..., 2] = (l1 - l2) * c * sn
+    yy, xx = np.mgrid[0:fh, 0:fw].astype(np.float32)
+    sh = np.stack([0.8 + 0.01 * xx, -1.7 + 0.015 * yy], -1).astype(np.float32)
+
+    def make():
+        raw, imgOut, tw, mask = _accum_inputs(141, W, H, W * s, H * s, nan_frac=0.0)
+        return raw, imgOut, tw, mask
+
+    raw, oi, ow, m = make()
+    orc.call("accumulateSuperResFull", raw, oi, ow, m, Tex(kp), Tex(sh), white, black, W, H, s, pitch_of(oi), pitch_of(m))
+    raw, hi, hw_, m = make()
+    hip.call("accumulateSuperResFull", raw, hi, hw_, m, Tex(kp), Tex(sh), white, black, W, H, s, pitch_of(hi), pitch_of(m))
+    np.testing.assert_allclose(hw_, ow, rtol=3e-5, atol=3e-5)
+    np.testing.assert_allclose(hi, oi, rtol=3e-5, atol=3e-5)
+
+
 @pytest.mark.parametrize("pair", [False, True])
 @pytest.mark.parametrize("pat", ["RGGB", "GRBG", "MONO"])
 def test_accumulate_x4_tile_kernel(orc, hip, pat, pair):
