@@ -67,9 +67,9 @@ def cpu_baseline(W, H, s, mono, sample_frames, seed):
     cfg = default_config(W, H, sample_frames, s, mono)
     op = OraclePipeline(cfg)
     t0 = time.perf_counter()
-    op.process(nf)
+    o_out, o_q = op.process(nf)
     dt = time.perf_counter() - t0
-    return {
+    res = {
         "value": round(sample_frames * W * H / dt / 1e6, 3),
         "unit": "Mpix/s",
         "cores": int(oracle().num_threads()),
@@ -77,6 +77,28 @@ def cpu_baseline(W, H, s, mono, sample_frames, seed):
         "sample": f"{sample_frames} frames of {W}x{H} (1 reference + {sample_frames - 1} moved), x{s}, "
                   f"whole pipeline, OpenMP, {dt:.1f} s",
     }
+    # the same sample through the HIP path: the "PSNR vs ref" half of BASELINE.json's metric (the oracle is
+    # only the checker here)
+    try:
+        import torch
+        from multi_frame_super_resolution_amd.pipeline import BurstPipeline
+        dev = torch.device("cuda", torch.cuda.current_device())
+        hp = BurstPipeline(cfg, dev)
+        h_out, h_q = hp.process([f.to(dev) for f in frames])
+        h_out = h_out.cpu().numpy()
+        h_q = h_q.cpu().numpy().view(np.uint16)
+        hp.close()
+        mse = float(np.mean((h_out.astype(np.float64) - o_out.astype(np.float64)) ** 2))
+        d8 = np.abs(np.round(h_out * 255.0) - np.round(o_out * 255.0))
+        d16 = np.abs(h_q.astype(np.int64) - o_q.astype(np.int64))
+        res["parity_on_sample"] = {
+            "psnr_db_vs_oracle": round(200.0 if mse == 0 else 10 * np.log10(1.0 / mse), 2),
+            "frac_gt_1lsb_8bit": float((d8 > 1).mean()),
+            "frac_gt_1lsb_16bit": float((d16 > 1).mean()),
+        }
+    except Exception as e:  # the throughput line must not depend on the checker
+        res["parity_on_sample"] = {"error": repr(e)}
+    return res
 
 
 def main():
