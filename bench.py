@@ -39,6 +39,7 @@ WORKLOADS = {
     "4k16_rggb_x2": (3840, 2160, 16, 2, False),      # BASELINE configs[2]
     "1080p5_gray_x2": (1920, 1080, 5, 2, True),      # BASELINE configs[1]
     "4k16_rggb_x4": (3840, 2160, 16, 4, False),      # BASELINE configs[3] (per GPU)
+    "8k8_rggb_x2": (7680, 4320, 8, 2, False),        # BASELINE configs[4]: 64-frame 8K burst = 8 frames per GPU at N = 8
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -307,7 +308,7 @@ def main():
             "data": "synthetic" + (", streamed from pinned host memory (4-deep device ring, copy stream)" if h2d else ""),
             "config": {
                 "workload": f"{n_frames}-frame {W}x{H} {'gray' if mono else 'RGGB u16'} burst -> x{s} "
-                            f"({args.workload}; BASELINE configs[{ {'4k16_rggb_x2': 2, '1080p5_gray_x2': 1, '4k16_rggb_x4': 3}[args.workload] }])",
+                            f"({args.workload}; BASELINE configs[{ {'4k16_rggb_x2': 2, '1080p5_gray_x2': 1, '4k16_rggb_x4': 3, '8k8_rggb_x2': 4}[args.workload] }])",
                 "frames_per_gpu": len(mine),
                 "burst_frames": n_frames,
                 "output_mpix_per_s": round(s * s * W * H * args.steps / dt / 1e6, 2),
