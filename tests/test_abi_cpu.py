@@ -57,6 +57,16 @@ def test_argument_validation_happens_on_the_host():
     got = (ctypes.c_int32 * 4)()
     assert raw["mfsr_get_cfa_pattern"](got) == 0 and list(got) == [2, 1, 1, 0]
     assert raw["mfsr_set_cfa_pattern"]((ctypes.c_int32 * 4)(0, 1, 1, 2)) == 0
+    # entry points added for the MI355X path validate the same way
+    assert raw["mfsr_tileSquaredSums"](None, None, 64, 64, 256, 4, 32, 2, 2, None) == -1
+    assert raw["mfsr_zeroRing_f32x4"](None, 64, 4, 4, None) == -1
+    assert raw["mfsr_burst_flush"](None, None) == -1
+    z3, t0 = capi.Float3(0, 0, 0), capi.Tex2D(None, 0, 0, 0)
+    assert raw["mfsr_accumulateSuperResFull2"](None, None, None, None, None, None, t0, t0, t0, z3, z3, 64, 64, 2, 768, 512,
+                                               None) == -1
+    cfgd = capi.Config()
+    assert raw["mfsr_config_default"](ctypes.byref(cfgd), 256, 192, 4, 2, 0) == 0
+    assert cfgd.pairFrames == 1 and cfgd.asyncFuse == 0
     assert L.raw["mfsr_error_string"](-1) == b"invalid argument"
     assert L.raw["mfsr_error_string"](0) == b"success"
 
