@@ -1,34 +1,31 @@
-// accumulate_fast.hip -- the x2 full-frame warp+fuse kernel of the headline
-// benchmark, restructured for CDNA4.  Same mathematics as
-// accumulateImagesSuperRes (reference test_opencv/DeBayerKernels.cu:379-468,
-// full-frame generalisation); same one-launch-per-frame structure with the
-// accumulators read-modify-written in HBM (48 B per HR pixel per frame).
+// accumulate_fast.hip -- the full-frame warp+fuse kernels of the headline benchmark (x2 and x4),
+// restructured for CDNA4.  Same mathematics as accumulateImagesSuperRes (reference
+// test_opencv/DeBayerKernels.cu:379-468, full-frame generalisation), accumulators in HBM as in the
+// reference (48 B per HR pixel and frame in its one-launch-per-frame structure; these kernels also take
+// two frames per launch and move them once for both).
 //
-// Why a second kernel: the straight port (accumulate.hip) spends its time in
-// VALU/SALU work, not in HBM -- per tap an IEEE division, a 3-way colour branch
-// and 16-byte certainty loads (measured 1.67 ms per 4K frame = 13 % of HBM peak).
-// This version removes that work without changing what is computed:
+// Why not the straight port (accumulate.hip): it spends its time in VALU/SALU work, not in HBM -- per tap
+// an IEEE division, a 3-way colour branch and a 16-byte certainty load (1.67 ms per 4K frame = 13 % of
+// HBM peak).  These kernels remove that work without changing what is computed:
 //
-//  * 4-pixel strips: one thread owns HR pixels X0..X0+3 of one row, so the two
-//    accumulator streams are three 16-byte loads/stores per lane (48 contiguous
-//    bytes per lane, 3 KiB contiguous per wavefront) and the certainty texel a
-//    tap reads, ((X+px)>>2), is a compile-time function of the pixel's position
-//    in the strip: 6 float4 loads per strip instead of 100.
-//  * 3x3 raw sites per pixel instead of 25 loads: the 5x5 HR taps of a x2 frame
-//    fall on a 3x3 raw neighbourhood; which site a tap hits depends only on the
-//    parity of (X + round(2u)), resolved with 16 v_cndmask per pixel.
-//  * no per-tap division: sum raw*w*c and w*c per CFA position, normalise once
-//    per pixel:  sum((raw-b)/wl * w*c) = (sum(raw*w*c) - b*sum(w*c)) / wl.
-//  * no colour branches: taps are summed per CFA-position class (row/column
-//    parity); classes map to R/G/B once per pixel (CFA is a template parameter).
-//  * 13 exponentials per pixel instead of 25: w(px,py) = w(-px,-py); evaluated
-//    with v_exp_f32.
+//  * 4-pixel strips: one thread owns HR pixels X0..X0+3 of one row; the certainty cell a tap reads is a
+//    compile-time function of the pixel's position in the strip (template parameter K).
+//  * raw sites instead of taps: the 5x5 HR taps of a pixel fall on 3x3 (x2) or 2x2 (x4) raw pixels.
+//    Which site a tap lands on depends on the low bits of (X + round(s*u)); that choice is applied to the
+//    WEIGHTS with lane masks (v_and / v_bitop3, no v_cndmask), the raw values enter with a few fma.
+//  * no per-tap division: sum raw*w*c and w*c per CFA position, normalise once per pixel:
+//    sum((raw-b)/wl * w*c) = (sum(raw*w*c) - b*sum(w*c)) / wl.
+//  * no colour branches: sites are summed per CFA-position class (row/column parity relative to the first
+//    site); classes map to R/G/B once per pixel (the CFA pattern is a template parameter).
+//  * 12 exponentials per pixel instead of 25: w(px,py) = w(-px,-py), v_exp_f32, exponents from sums.
+//  * LDS tile kernels (fields at the tracking resolution): field / certainty texels, interpolation
+//    fractions and the accumulator rows (LDS-DMA) staged per workgroup; see k_accumulate2xTile.
 //
-// Numerics: the weights and the flow rounding are the same expressions as the
-// straight kernel; the per-channel sums are re-associated (class sums, one
-// normalisation), so results agree with it to ~1e-6 relative (tests: 2e-5), not
-// bit for bit.  Pixels whose taps would be clamped at the frame border (or whose
-// flow is wild) take the straight per-pixel path inside the same launch.
+// Numerics: the flow rounding is the same expression as in the straight kernel and the oracle; weights
+// and per-channel sums are re-associated (pre-scaled exponents, class sums, fma, one normalisation), so
+// results agree with the straight kernel to ~1e-6 relative (tests: 3e-5), not bit for bit.  Pixels whose
+// taps would be clamped at the frame border, strips with wild flow and strips whose kernel parameters
+// are not positive semi-definite take the straight per-pixel arithmetic (margin kernel / in-kernel path).
 #include <cstdlib>
 
 #include "accumulate_common.hpp"
