@@ -250,6 +250,12 @@ int mfsr_resampleFloat3(const mfsr_float3* in, int inPitch, int inW, int inH, mf
 int mfsr_quantize(const mfsr_float3* in, int inPitch, uint16_t* out16, uint8_t* out8, int width, int height,
                   float maxOut, mfsr_stream_t stream);
 int mfsr_fill_f32(float* dst, size_t count, float value, mfsr_stream_t stream);
+/* deBayersSubSample3 (A1) + mfsr_rgbToGray + mfsr_separableFilter + the first mfsr_downsample2x in one
+ * launch (what the burst driver does to every Bayer frame before tracking); bit-identical to the chain.
+ * dimX x dimY is the half-resolution size; pyr1 may be NULL; ntaps odd, <= 17. */
+int mfsr_prepareFrameFused(const uint16_t* dataIn, mfsr_float3* halfOut, int halfPitch, float maxVal, int dimX, int dimY,
+                           float* pyr0, int pyr0Pitch, float* pyr1, int pyr1Pitch, const float* taps, int ntaps,
+                           mfsr_stream_t stream);
 /* one-pixel border ring of a float4 image := 0: what ComputeRobustnessMask (:37) leaves unwritten */
 int mfsr_zeroRing_f32x4(mfsr_float4* img, int pitch, int width, int height, mfsr_stream_t stream);
 /* variant selector of the accumulate kernels (tests, A/B benchmarks):

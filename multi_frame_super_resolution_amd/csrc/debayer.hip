@@ -72,6 +72,127 @@ extern "C" int mfsr_deBayersSubSample3(const uint16_t* dataIn, mfsr_float3* imgO
     return mfsr_launch_status("deBayersSubSample3");
 }
 
+// ---- A1 + gray + separable prefilter + first pyramid level in one launch ------------------
+// What the burst driver does to every frame before tracking: deBayersSubSample3 (A1), luma of the
+// half-res RGB, the separable Gaussian prefilter (gaussin_filter_1D taps, clamped borders) and the
+// 2x2 mean of the first pyramid level -- five launches and 95 MB of intermediate traffic per 4K frame.
+// Here a 64 x 16 tile of the tracking image + a (taps/2)-pixel halo is built in LDS straight from the
+// raw quads; every value is computed by the very expressions of the five kernels, in their order
+// (halo samples are the samples at the clamped coordinates, which is what the filters read), so the
+// three outputs are bit-identical to the chain.
+#define PREP_TX 64
+#define PREP_TY 16
+#define PREP_MAXC0 8
+struct PrepTaps {
+    float t[2 * PREP_MAXC0 + 1];
+    int n;
+};
+
+__device__ __forceinline__ pix3 a1_pixel(const uint16_t* __restrict__ dataIn, int dimX, int x, int y, float factor, int cfa)
+{
+    const size_t rowElems = (size_t)dimX * 2;
+    const uint32_t top = *(const uint32_t*)(dataIn + (size_t)(2 * y) * rowElems + 2 * x);
+    const uint32_t bot = *(const uint32_t*)(dataIn + (size_t)(2 * y + 1) * rowElems + 2 * x);
+    const float raw[2][2] = {{(float)(top & 0xffffu), (float)(top >> 16)}, {(float)(bot & 0xffffu), (float)(bot >> 16)}};
+    pix3 pixel = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ix = 0; ix < 2; ix++) {
+#pragma unroll
+        for (int iy = 0; iy < 2; iy++) {
+            const int c = cfa_at(cfa, iy, ix);
+            const float v = raw[iy][ix] * factor;
+            if (c == MFSR_GREEN)
+                pixel.y += v * 0.5f;
+            else if (c == MFSR_RED)
+                pixel.x = v;
+            else if (c == MFSR_BLUE)
+                pixel.z = v;
+        }
+    }
+    return pixel;
+}
+
+__global__ void __launch_bounds__(256)
+    k_prepareFrameFused(const uint16_t* __restrict__ dataIn, pix3* __restrict__ halfOut, int halfPitch, float maxVal,
+                        int dimX, int dimY, float* __restrict__ pyr0, int pyr0Pitch, float* __restrict__ pyr1,
+                        int pyr1Pitch, PrepTaps taps, int cfa)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_prep[];
+    const int c0 = taps.n / 2;
+    const int GW = PREP_TX + 2 * c0, GH = PREP_TY + 2 * c0;
+    float* sG = s_prep;              // GH x GW luma of tile + halo
+    float* sH = sG + GW * GH;        // GH x PREP_TX after the row pass
+    float* sO = sH + PREP_TX * GH;   // PREP_TY x PREP_TX filtered tile
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int x0 = blockIdx.x * PREP_TX, y0 = blockIdx.y * PREP_TY;
+    const float factor = 1.0f / maxVal;
+
+    for (int i = tid; i < GW * GH; i += 256) {
+        const int ly = i / GW, lx = i - ly * GW;
+        const int gx = x0 + lx - c0, gy = y0 + ly - c0;
+        const int cx = clampi(gx, 0, dimX - 1), cy = clampi(gy, 0, dimY - 1);
+        const pix3 p = a1_pixel(dataIn, dimX, cx, cy, factor, cfa);
+        if (gx == cx && gy == cy && lx >= c0 && lx < c0 + PREP_TX && ly >= c0 && ly < c0 + PREP_TY) row_ptr(halfOut, halfPitch, gy)[gx] = p;
+        sG[i] = 0.299f * p.x + 0.587f * p.y + 0.114f * p.z;  // k_rgbToGray
+    }
+    __syncthreads();
+    for (int i = tid; i < PREP_TX * GH; i += 256) {
+        const int ly = i / PREP_TX, lx = i - ly * PREP_TX;
+        // k_filter1d<true> at column x0+lx of (clamped) row: taps read clamp(x + t - c0); the halo already
+        // holds the clamped-coordinate samples, except that a column beyond the image must itself behave
+        // like the clamped column -- those outputs are never used (masked at the store)
+        float s = 0;
+        for (int t = 0; t < taps.n; t++) s += taps.t[t] * sG[ly * GW + lx + t];
+        sH[i] = s;
+    }
+    __syncthreads();
+    {
+        const int lx = threadIdx.x;
+#pragma unroll
+        for (int r = 0; r < PREP_TY / 4; r++) {
+            const int ly = threadIdx.y + 4 * r;
+            float s = 0;
+            for (int t = 0; t < taps.n; t++) s += taps.t[t] * sH[(ly + t) * PREP_TX + lx];
+            sO[ly * PREP_TX + lx] = s;
+            const int gx = x0 + lx, gy = y0 + ly;
+            if (gx < dimX && gy < dimY) row_ptr(pyr0, pyr0Pitch, gy)[gx] = s;
+        }
+    }
+    if (pyr1 == nullptr) return;
+    __syncthreads();
+    {
+        // k_downsample2x on the filtered tile: 32 x 8 outputs
+        const int ox = tid & 31, oy = tid >> 5;  // 256 threads = 32 x 8
+        const int gx = x0 / 2 + ox, gy = y0 / 2 + oy;
+        if (gx < dimX / 2 && gy < dimY / 2) {
+            const float ax = sO[(2 * oy) * PREP_TX + 2 * ox], ay = sO[(2 * oy) * PREP_TX + 2 * ox + 1];
+            const float bx = sO[(2 * oy + 1) * PREP_TX + 2 * ox], by = sO[(2 * oy + 1) * PREP_TX + 2 * ox + 1];
+            row_ptr(pyr1, pyr1Pitch, gy)[gx] = ((ax + ay) + (bx + by)) * 0.25f;
+        }
+    }
+}
+
+extern "C" int mfsr_prepareFrameFused(const uint16_t* dataIn, mfsr_float3* halfOut, int halfPitch, float maxVal, int dimX,
+                                      int dimY, float* pyr0, int pyr0Pitch, float* pyr1, int pyr1Pitch, const float* taps,
+                                      int ntaps, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(dataIn && halfOut && pyr0 && taps && dimX > 0 && dimY > 0);
+    MFSR_REQUIRE((long long)halfPitch >= 12LL * dimX && (halfPitch & 3) == 0 && ((uintptr_t)dataIn & 3) == 0);
+    MFSR_REQUIRE((long long)pyr0Pitch >= 4LL * dimX && (pyr0Pitch & 3) == 0);
+    MFSR_REQUIRE(ntaps > 0 && (ntaps & 1) == 1);
+    if (ntaps / 2 > PREP_MAXC0) return MFSR_E_UNSUPPORTED;
+    if (pyr1) MFSR_REQUIRE((long long)pyr1Pitch >= 4LL * (dimX / 2) && (pyr1Pitch & 3) == 0 && dimX >= 2 && dimY >= 2);
+    PrepTaps tp;
+    tp.n = ntaps;
+    for (int i = 0; i < ntaps; i++) tp.t[i] = taps[i];
+    const int c0 = ntaps / 2, GW = PREP_TX + 2 * c0, GH = PREP_TY + 2 * c0;
+    const size_t lds = sizeof(float) * ((size_t)GW * GH + (size_t)PREP_TX * GH + (size_t)PREP_TX * PREP_TY);
+    dim3 block(64, 4), grid(mfsr_cdiv(dimX, PREP_TX), mfsr_cdiv(dimY, PREP_TY));
+    hipLaunchKernelGGL(k_prepareFrameFused, grid, block, lds, mfsr_s(stream), dataIn, (pix3*)halfOut, halfPitch, maxVal, dimX,
+                       dimY, pyr0, pyr0Pitch, pyr1, pyr1Pitch, tp, mfsr_cfa_packed());
+    return mfsr_launch_status("prepareFrameFused");
+}
+
 // ---- A2: deBayerGreenKernel (DeBayerKernels.cu:55-149) ------------------------
 struct Lvl {
     float bp[3], sc[3];

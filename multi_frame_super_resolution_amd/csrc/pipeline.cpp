@@ -413,6 +413,17 @@ static int prepare_frame(mfsr_burst* b, const uint16_t* raw, Img& half, Img* pyr
     Layout& L = b->L;
     TRY(mfsr_set_cfa_pattern(c.cfa));
     const float maxValEff = c.mono ? 2.0f * c.maxVal : c.maxVal;  // mono: 4 "greens" x 0.5 -> mean of the quad
+    const int nlev = ilog2(L.maxFactor) + 1;
+    if (c.fused && !c.mono && b->ntaps / 2 <= 8 && L.tw == L.hw && L.th == L.hh) {
+        // A1 + luma + prefilter + first pyramid level in one launch (bit-identical to the chain below)
+        TRY(mfsr_prepareFrameFused(raw, (mfsr_float3*)half.ptr, half.pitch, maxValEff, L.hw, L.hh, (float*)pyr[0].ptr,
+                                   pyr[0].pitch, nlev > 1 ? (float*)pyr[1].ptr : nullptr, nlev > 1 ? pyr[1].pitch : 0,
+                                   b->taps, b->ntaps, stream));
+        for (int i = 2; i < nlev; i++)
+            TRY(mfsr_downsample2x((const float*)pyr[i - 1].ptr, pyr[i - 1].pitch, (float*)pyr[i].ptr, pyr[i].pitch, pyr[i].w,
+                                  pyr[i].h, stream));
+        return MFSR_OK;
+    }
     TRY(mfsr_deBayersSubSample3(raw, (mfsr_float3*)half.ptr, maxValEff, L.hw, L.hh, half.pitch, stream));
     if (c.mono)
         TRY(mfsr_u16ToFloat(raw, (float*)L.tmpA.ptr, L.tmpA.pitch, L.W, L.H, 1.0f / c.maxVal, stream));

@@ -7,6 +7,8 @@ Tolerances (north_star: +-1 LSB on outputs, DeBayer bit-exact):
   * kernels with transcendentals (exp, pow, sin/cos/atan2) or re-ordered sums:
     the tolerance is written next to each assertion.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -321,6 +323,35 @@ def test_accumulate_x4_tile_kernel(orc, hip, pat, pair):
         hip.L.set_accumulate_fast_exp(2)
         np.testing.assert_allclose(hi, si, rtol=1e-5, atol=1e-5)
         assert not np.array_equal(hi, si) or pat == "MONO"
+
+
+@pytest.mark.parametrize("W,H,sigma", [(192, 96, 0.5), (152, 70, 1.2)])
+def test_prepareFrameFused_equals_chain(orc, hip, W, H, sigma):
+    """A1 + luma + separable prefilter + 2x2 mean in one launch == the four-kernel chain, bit for bit
+    (ragged tiles, clamped borders, odd half-resolution sizes)."""
+    orc.set_cfa(RGGB)
+    hip.set_cfa(RGGB)
+    raw = rng(150).integers(0, 4096, (H, W), dtype=np.uint16)
+    hw, hh = W // 2, H // 2
+    taps = np.zeros(99, np.float32)
+    n = hip.L.raw["mfsr_gaussin_filter_1D"](sigma, taps.ctypes.data_as(ctypes.c_void_p))
+    assert 3 <= n <= 17
+    half = np.zeros((hh, hw, 3), np.float32)
+    gray = np.zeros((hh, hw), np.float32)
+    tmp = np.zeros_like(gray)
+    p0 = np.zeros_like(gray)
+    p1 = np.zeros((hh // 2, hw // 2), np.float32)
+    hip.call("deBayersSubSample3", raw, half, 4095.0, hw, hh, pitch_of(half))
+    hip.call("rgbToGray", half, pitch_of(half), gray, pitch_of(gray), hw, hh)
+    hip.call("separableFilter", gray, pitch_of(gray), tmp, p0, pitch_of(p0), hw, hh, 1, Host(taps), n)
+    hip.call("downsample2x", p0, pitch_of(p0), p1, pitch_of(p1), hw // 2, hh // 2)
+    fh = np.zeros_like(half)
+    f0 = np.zeros_like(p0)
+    f1 = np.zeros_like(p1)
+    hip.call("prepareFrameFused", raw, fh, pitch_of(fh), 4095.0, hw, hh, f0, pitch_of(f0), f1, pitch_of(f1), Host(taps), n)
+    assert_bitexact(half, fh, "half-res RGB")
+    assert_bitexact(p0, f0, "prefiltered luma")
+    assert_bitexact(p1, f1, "pyramid level 1")
 
 
 def test_accumulateImages_x1(orc, hip):
