@@ -139,12 +139,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    # MFSR_DIST_BACKEND=gloo: rehearsal of the multi-rank schedule on a box with fewer GPUs than ranks (the
+    # ranks share GPUs, collectives are staged through the host); the measured runs use RCCL ("nccl")
+    backend = os.environ.get("MFSR_DIST_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from multi_frame_super_resolution_amd import distributed as mdist
     from multi_frame_super_resolution_amd.pipeline import BurstPipeline, default_config
@@ -315,6 +323,8 @@ def main():
                 "parallelism": "1 GPU" if world == 1 else f"frame-shard x{world} + RCCL {args.exchange} of HR accumulators"
                                + (" overlapped with the next burst's compute" if pipelined else ""),
                 "kernels": "unfused (one launch per reference kernel)" if args.unfused else "fused",
+                **({"rehearsal": "gloo backend, ranks share GPUs, collectives staged through the host: not a measurement"}
+                   if (world > 1 and backend == "gloo") else {}),
             },
             "roofline": {
                 "kernel": ("k_accumulate2xTile / k_accumulate2xStrip" if s == 2 else "k_accumulateSuperRes<GEOM_FULL,fast>")

@@ -36,6 +36,22 @@ import torch
 import torch.distributed as dist
 
 
+def _staged(group) -> bool:
+    """gloo moves host memory only (reduce / gather have no GPU path): a rehearsal of the multi-rank
+    schedule on fewer GPUs than ranks (``MFSR_DIST_BACKEND=gloo`` in bench.py) stages through the host."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _reduce_to(t: torch.Tensor, dst: int, group):
+    if _staged(group) and t.is_cuda:
+        h = t.cpu()
+        dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_rank(group) == dst:
+            t.copy_(h)
+    else:
+        dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
+
+
 def frames_of_rank(n_frames: int, rank: int, world: int) -> List[int]:
     """Round-robin frame shard: rank g owns frames {k : k mod world == g}."""
     return [k for k in range(n_frames) if k % world == rank]
@@ -69,8 +85,8 @@ def exchange_and_finish(pipe, mode: str = "auto", group=None):
         _, out16 = pipe.finish(want_float=False, want_u16=True)
         return out16
     if mode == "reduce":
-        dist.reduce(pipe.img_out, dst=0, op=dist.ReduceOp.SUM, group=group)
-        dist.reduce(pipe.total_weights, dst=0, op=dist.ReduceOp.SUM, group=group)
+        _reduce_to(pipe.img_out, 0, group)
+        _reduce_to(pipe.total_weights, 0, group)
         if rank == 0:
             _, out16 = pipe.finish(want_float=False, want_u16=True)
             return out16
@@ -86,6 +102,16 @@ def exchange_and_finish(pipe, mode: str = "auto", group=None):
     # gather as bytes: neither RCCL nor gloo has a 16-bit integer type
     out8 = out16.view(torch.uint8)
     stripe = out8[row0:row0 + rows]
+    if _staged(group) and stripe.is_cuda:
+        hs = stripe.cpu()
+        if rank == 0:
+            hparts = [torch.empty_like(hs) for _ in range(world)]
+            dist.gather(hs, gather_list=hparts, dst=0, group=group)
+            for r in range(world):
+                out8[r * rows:(r + 1) * rows].copy_(hparts[r])
+            return out16
+        dist.gather(hs, gather_list=None, dst=0, group=group)
+        return None
     if rank == 0:
         parts = [out8[r * rows:(r + 1) * rows] for r in range(world)]
         dist.gather(stripe, gather_list=parts, dst=0, group=group)
@@ -99,9 +125,9 @@ def _reduce_scatter_rows(acc: torch.Tensor, rows: int, rank: int, world: int, gr
     chunk = flat.numel() // world
     out = flat[rank * chunk:(rank + 1) * chunk]
     if dist.get_backend(group) == "gloo":
-        # gloo has no reduce_scatter: emulate with per-chunk reduces (CPU tests only)
+        # gloo has no reduce_scatter: emulate with per-chunk reduces (CPU tests / rehearsals only)
         for r in range(world):
-            dist.reduce(flat[r * chunk:(r + 1) * chunk], dst=r, op=dist.ReduceOp.SUM, group=group)
+            _reduce_to(flat[r * chunk:(r + 1) * chunk], r, group)
         return
     tmp = torch.empty_like(out)
     dist.reduce_scatter_tensor(tmp, flat, op=dist.ReduceOp.SUM, group=group)
