@@ -157,7 +157,8 @@ __device__ __forceinline__ void classes_to_channels(const float (&S)[2][2], cons
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        accP[3 * K + c] += (chS[c] - lv.black[c] * chW[c]) * lv.invWhite[c];
+        // (chS - black * chW) / white, added to the strip's sum: two fma
+        accP[3 * K + c] = __builtin_fmaf(__builtin_fmaf(-lv.black[c], chW[c], chS[c]), lv.invWhite[c], accP[3 * K + c]);
         accW[3 * K + c] += chW[c];
     }
 }
