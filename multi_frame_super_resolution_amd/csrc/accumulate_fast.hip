@@ -336,18 +336,25 @@ __global__ void __launch_bounds__(256)
 
 // FR = HR pixels per field texel along each axis (4: fields at LR/2, the Bayer
 // pipeline; 2: fields at LR, the monochrome pipeline; 0: any size, per-pixel fetch).
-template <int CFA, int FR>
-__global__ void __launch_bounds__(256)
-    k_accumulate2xStrip(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
-                        const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
-                        StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
-{
-    const int tx = blockIdx.x * 64 + threadIdx.x;
-    const int Y = blockIdx.y * 4 + threadIdx.y;
-    const int hrW = 2 * dimX, hrH = 2 * dimY;
-    const int X0 = 4 * tx;
-    if (X0 < STRIP_MARGIN || X0 >= hrW - STRIP_MARGIN || Y < STRIP_MARGIN || Y >= hrH - STRIP_MARGIN) return;
+// per-frame arguments of the multi-frame kernels
+struct TileFrame {
+    const uint16_t* raw;
+    const float4* mask;
+    mfsr_tex2d shifts;
+};
+template <int NF>
+struct TileFrames {
+    TileFrame f[NF];
+};
 
+// one frame of one strip on the register-resident accumulators (k_accumulate2xStrip)
+template <int CFA, int FR>
+__device__ __forceinline__ void strip_frame(int tx, int Y, int X0, const uint16_t* __restrict__ raw,
+                                            const float4* __restrict__ certaintyMask, const mfsr_tex2d& kernelParam,
+                                            const mfsr_tex2d& shifts, const Levels3& glv, const StripLevels& lv, int dimX,
+                                            int dimY, int strideMask, int cfaPacked, float* accP, float* accW)
+{
+    const int hrW = 2 * dimX, hrH = 2 * dimY;
     const float posY = ((float)Y + 0.5f) / (float)hrH;
     int sx[4], sy[4];
     float kx[4], ky[4], kz[4];
@@ -423,29 +430,20 @@ __global__ void __launch_bounds__(256)
         safe = safe && sx[k] > -(1 << 20) && sx[k] < (1 << 20) && sy[k] > -(1 << 20) && sy[k] < (1 << 20);
     }
     if (!safe) {
+        // border-free but wild-flow / non-PSD strips: the straight per-pixel arithmetic on the register values
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
             const int X = X0 + k;
-            if (X >= 1 && X < hrW - 1)
-                accumulate_pixel_generic<GEOM_FULL, true>(X, Y, raw, imgOut, totalWeights, certaintyMask, kernelParam,
-                                                          shifts, glv, dimX, dimY, 2, strideOut, strideMask, cfaPacked);
+            if (X >= 1 && X < hrW - 1) {
+                pix3 px = {accP[3 * k], accP[3 * k + 1], accP[3 * k + 2]};
+                pix3 tw = {accW[3 * k], accW[3 * k + 1], accW[3 * k + 2]};
+                accumulate_pixel_core<GEOM_FULL, true>(X, Y, raw, certaintyMask, kernelParam, shifts, glv, dimX, dimY, 2,
+                                                       strideMask, cfaPacked, px, tw);
+                accP[3 * k] = px.x; accP[3 * k + 1] = px.y; accP[3 * k + 2] = px.z;
+                accW[3 * k] = tw.x; accW[3 * k + 1] = tw.y; accW[3 * k + 2] = tw.z;
+            }
         }
         return;
-    }
-
-    // accumulators: 4 pixels x 3 channels = 48 contiguous bytes per plane-set
-    float4* pP = (float4*)((char*)imgOut + (size_t)Y * strideOut + (size_t)X0 * 12);
-    float4* pW = (float4*)((char*)totalWeights + (size_t)Y * strideOut + (size_t)X0 * 12);
-    float accP[12], accW[12];
-    {
-        const float4 a0 = pP[0], a1 = pP[1], a2 = pP[2];
-        const float4 b0 = pW[0], b1 = pW[1], b2 = pW[2];
-        accP[0] = a0.x; accP[1] = a0.y; accP[2] = a0.z; accP[3] = a0.w;
-        accP[4] = a1.x; accP[5] = a1.y; accP[6] = a1.z; accP[7] = a1.w;
-        accP[8] = a2.x; accP[9] = a2.y; accP[10] = a2.z; accP[11] = a2.w;
-        accW[0] = b0.x; accW[1] = b0.y; accW[2] = b0.z; accW[3] = b0.w;
-        accW[4] = b1.x; accW[5] = b1.y; accW[6] = b1.z; accW[7] = b1.w;
-        accW[8] = b2.x; accW[9] = b2.y; accW[10] = b2.z; accW[11] = b2.w;
     }
 
     // certainty texels: rows (Y-2)>>2 and (Y+2)>>2, cells tx-1, tx, tx+1; non-finite -> 0 (:438-439)
@@ -472,6 +470,39 @@ __global__ void __launch_bounds__(256)
     strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kx[2], ky[2], kz[2], raw, dimX, mval, lv, accP, accW);
     strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kx[3], ky[3], kz[3], raw, dimX, mval, lv, accP, accW);
 
+}
+
+// Register-only strip kernel: serves every field resolution (FR) without LDS; NF frames add into the
+// accumulators while they sit in registers (one read-modify-write of HBM for both).
+template <int CFA, int FR, int NF>
+__global__ void __launch_bounds__(256)
+    k_accumulate2xStrip(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
+                        Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
+{
+    const int tx = blockIdx.x * 64 + threadIdx.x;
+    const int Y = blockIdx.y * 4 + threadIdx.y;
+    const int hrW = 2 * dimX, hrH = 2 * dimY;
+    const int X0 = 4 * tx;
+    if (X0 < STRIP_MARGIN || X0 >= hrW - STRIP_MARGIN || Y < STRIP_MARGIN || Y >= hrH - STRIP_MARGIN) return;
+
+    // accumulators: 4 pixels x 3 channels = 48 contiguous bytes per plane-set
+    float4* pP = (float4*)((char*)imgOut + (size_t)Y * strideOut + (size_t)X0 * 12);
+    float4* pW = (float4*)((char*)totalWeights + (size_t)Y * strideOut + (size_t)X0 * 12);
+    float accP[12], accW[12];
+    {
+        const float4 a0 = pP[0], a1 = pP[1], a2 = pP[2];
+        const float4 b0 = pW[0], b1 = pW[1], b2 = pW[2];
+        accP[0] = a0.x; accP[1] = a0.y; accP[2] = a0.z; accP[3] = a0.w;
+        accP[4] = a1.x; accP[5] = a1.y; accP[6] = a1.z; accP[7] = a1.w;
+        accP[8] = a2.x; accP[9] = a2.y; accP[10] = a2.z; accP[11] = a2.w;
+        accW[0] = b0.x; accW[1] = b0.y; accW[2] = b0.z; accW[3] = b0.w;
+        accW[4] = b1.x; accW[5] = b1.y; accW[6] = b1.z; accW[7] = b1.w;
+        accW[8] = b2.x; accW[9] = b2.y; accW[10] = b2.z; accW[11] = b2.w;
+    }
+#pragma unroll
+    for (int n = 0; n < NF; n++)
+        strip_frame<CFA, FR>(tx, Y, X0, fr.f[n].raw, fr.f[n].mask, kernelParam, fr.f[n].shifts, glv, lv, dimX, dimY, strideMask,
+                             cfaPacked, accP, accW);
     pP[0] = make_float4(accP[0], accP[1], accP[2], accP[3]);
     pP[1] = make_float4(accP[4], accP[5], accP[6], accP[7]);
     pP[2] = make_float4(accP[8], accP[9], accP[10], accP[11]);
@@ -503,15 +534,6 @@ __global__ void __launch_bounds__(256)
 // NF frames per launch (1 or 2).  Everything that does not depend on the frame is done once for
 // both: the accumulator staging and write-back (the 48 B/px/frame of HBM traffic become 24), the
 // kernel-parameter mix, the column/row fractions.  The two frames add into the same registers.
-struct TileFrame {
-    const uint16_t* raw;
-    const float4* mask;
-    mfsr_tex2d shifts;
-};
-template <int NF>
-struct TileFrames {
-    TileFrame f[NF];
-};
 
 template <int CFA, int NF>
 __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
@@ -1067,28 +1089,22 @@ void launch_tile(dim3 grid, dim3 block, hipStream_t st, const TileFrames<NF>& fr
                        imgOut, tw, kp, glv, lv, dimX, dimY, strideOut, strideMask, cfaPacked, tilesX, tilesY, tilesPerXcd);
 }
 
-template <int CFA>
-void launch_strip(dim3 grid, dim3 block, hipStream_t st, const uint16_t* raw, pix3* imgOut, pix3* tw, const float4* mask,
-                  mfsr_tex2d kp, mfsr_tex2d sh, Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut,
-                  int strideMask, int cfaPacked)
+template <int CFA, int NF>
+void launch_strip_regs(dim3 grid, dim3 block, hipStream_t st, const TileFrames<NF>& fr, pix3* imgOut, pix3* tw, mfsr_tex2d kp,
+                       Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
 {
     const int hrW = 2 * dimX, hrH = 2 * dimY;
-    const bool same = kp.width == sh.width && kp.height == sh.height;
-    if (tile_kernel_ok(kp, sh, dimX, dimY)) {
-        TileFrames<1> fr;
-        fr.f[0].raw = raw;
-        fr.f[0].mask = mask;
-        fr.f[0].shifts = sh;
-        launch_tile<CFA, 1>(grid, block, st, fr, imgOut, tw, kp, glv, lv, dimX, dimY, strideOut, strideMask, cfaPacked);
-    } else if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4)
-        hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 4>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
-                           dimY, strideOut, strideMask, cfaPacked);
+    bool same = true;
+    for (int n = 0; n < NF; n++) same = same && kp.width == fr.f[n].shifts.width && kp.height == fr.f[n].shifts.height;
+    if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4)
+        hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 4, NF>), grid, block, 0, st, fr, imgOut, tw, kp, glv, lv, dimX, dimY,
+                           strideOut, strideMask, cfaPacked);
     else if (same && kp.width * 2 == hrW && kp.height * 2 == hrH && kp.width >= 4)
-        hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 2>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
-                           dimY, strideOut, strideMask, cfaPacked);
+        hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 2, NF>), grid, block, 0, st, fr, imgOut, tw, kp, glv, lv, dimX, dimY,
+                           strideOut, strideMask, cfaPacked);
     else
-        hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 0>), grid, block, 0, st, raw, imgOut, tw, mask, kp, sh, glv, lv, dimX,
-                           dimY, strideOut, strideMask, cfaPacked);
+        hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 0, NF>), grid, block, 0, st, fr, imgOut, tw, kp, glv, lv, dimX, dimY,
+                           strideOut, strideMask, cfaPacked);
 }
 
 void read_env_once()
@@ -1161,12 +1177,29 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
                                                  strideMask, cp);                                                      \
             launch_margin(0);                                                                                          \
             launch_margin(1);                                                                                          \
-        } else {                                                                                                       \
-            for (int n = 0; n < nFrames; n++) {                                                                        \
-                launch_strip<pack_cfa(a, b, c, d)>(grid, block, st, dataIn[n], pI, pT, (const float4*)certaintyMask[n], \
-                                                  kernelParam, shifts[n], glv, lv, dimX, dimY, strideOut, strideMask, cp); \
-                launch_margin(n);                                                                                      \
+        } else if (nFrames == 2) {                                                                                     \
+            TileFrames<2> fr;                                                                                          \
+            for (int n = 0; n < 2; n++) {                                                                              \
+                fr.f[n].raw = dataIn[n];                                                                               \
+                fr.f[n].mask = (const float4*)certaintyMask[n];                                                        \
+                fr.f[n].shifts = shifts[n];                                                                            \
             }                                                                                                          \
+            launch_strip_regs<pack_cfa(a, b, c, d), 2>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY,  \
+                                                       strideOut, strideMask, cp);                                     \
+            launch_margin(0);                                                                                          \
+            launch_margin(1);                                                                                          \
+        } else {                                                                                                       \
+            TileFrames<1> fr;                                                                                          \
+            fr.f[0].raw = dataIn[0];                                                                                   \
+            fr.f[0].mask = (const float4*)certaintyMask[0];                                                            \
+            fr.f[0].shifts = shifts[0];                                                                                \
+            if (tile_kernel_ok(kernelParam, shifts[0], dimX, dimY))                                                    \
+                launch_tile<pack_cfa(a, b, c, d), 1>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY,    \
+                                                     strideOut, strideMask, cp);                                       \
+            else                                                                                                       \
+                launch_strip_regs<pack_cfa(a, b, c, d), 1>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX,    \
+                                                           dimY, strideOut, strideMask, cp);                           \
+            launch_margin(0);                                                                                          \
         }                                                                                                              \
         return 1;
     switch (packed2) {
