@@ -207,7 +207,7 @@ def main():
         main = torch.cuda.current_stream()
         ev_up = [torch.cuda.Event() for _ in order]
         ev_done = [torch.cuda.Event() for _ in order]
-        pipe.reset_accumulators()
+        pipe.begin_burst()
         for i, k in enumerate(order):
             with torch.cuda.stream(copy_s):
                 if i >= 4:

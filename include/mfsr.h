@@ -119,6 +119,14 @@ int mfsr_accumulateSuperResFull2(const uint16_t* dataIn0, const uint16_t* dataIn
                                  mfsr_tex2d shifts1, mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY,
                                  int scale, int strideOut, int strideMask, mfsr_stream_t stream);
 
+/* nFrames (1 or 2) frames in one call (dataIn / certaintyMask / shifts: host arrays of nFrames entries).
+ * accumulatorsUndefined != 0: imgOut / totalWeights are OVERWRITTEN as if they had been zeroed before
+ * the call -- the first launch of a burst needs neither the memset nor the read of the two planes. */
+int mfsr_accumulateSuperResFullN(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                                 const mfsr_float4* const* certaintyMask, mfsr_tex2d kernelParam, const mfsr_tex2d* shifts,
+                                 mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int scale,
+                                 int strideOut, int strideMask, int accumulatorsUndefined, mfsr_stream_t stream);
+
 /* ---- B/E/H/I: kernel.cu --------------------------------------------------- */
 int mfsr_squaredSum(const float* inTiles, float* outValues, int maxShift, int tileSize, int tileCount,
                     mfsr_stream_t stream); /* :119 */
@@ -363,6 +371,10 @@ int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, mfsr_stream_
  * buffer handed to add_frame must stay untouched until one of those has been issued. */
 int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float3* imgOut,
                          mfsr_float3* totalWeights, mfsr_stream_t stream);
+/* Start a new burst on these accumulators WITHOUT zeroing them: the first warp+fuse launch that follows
+ * overwrites them (as if zeroed), which saves the memset and the first read of both planes.  If no frame
+ * is added before flush / finish, they are zeroed then.  Without this call the caller zeroes them. */
+int mfsr_burst_begin(mfsr_burst* b, mfsr_float3* imgOut, mfsr_float3* totalWeights, mfsr_stream_t stream);
 /* fuse a frame that is still waiting for its partner and make the caller's stream wait for every fuse issued so far */
 int mfsr_burst_flush(mfsr_burst* b, mfsr_stream_t stream);
 /* ApplyWeighting (+fallback) + optional gamma; outImg float3 HR (may be NULL),

@@ -107,13 +107,13 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
                                        mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
                                        mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
                                        mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
-                                       mfsr_stream_t stream);  // accumulate_fast.hip
+                                       int fresh, mfsr_stream_t stream);  // accumulate_fast.hip
 
 int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
                                       mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
                                       mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
                                       mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
-                                      mfsr_stream_t stream);  // accumulate_fast.hip
+                                      int fresh, mfsr_stream_t stream);  // accumulate_fast.hip
 
 static int check_superres_args(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
                                const mfsr_float4* certaintyMask, const mfsr_tex2d& kernelParam, const mfsr_tex2d& shifts,
@@ -161,11 +161,11 @@ extern "C" int mfsr_accumulateSuperResFull(const uint16_t* dataIn, mfsr_float3* 
     if (rc) return rc;
     if (g_accumulate_fast == 2 && scale == 2 &&
         mfsr_try_launch_accumulate2x_strip(1, &dataIn, imgOut, totalWeights, &certaintyMask, kernelParam, &shifts, whiteLevel,
-                                           blackLevel, dimX, dimY, strideOut, strideMask, stream) == 1)
+                                           blackLevel, dimX, dimY, strideOut, strideMask, 0, stream) == 1)
         return mfsr_launch_status("accumulateSuperResFull(strip)");
     if (g_accumulate_fast == 2 && scale == 4 &&
         mfsr_try_launch_accumulate4x_tile(1, &dataIn, imgOut, totalWeights, &certaintyMask, kernelParam, &shifts, whiteLevel,
-                                          blackLevel, dimX, dimY, strideOut, strideMask, stream) == 1)
+                                          blackLevel, dimX, dimY, strideOut, strideMask, 0, stream) == 1)
         return mfsr_launch_status("accumulateSuperResFull(x4 tile)");
     dim3 block(64, 4), grid(mfsr_cdiv((long long)dimX * scale, 64), mfsr_cdiv((long long)dimY * scale, 4));
     const Levels3 lv = make_levels(whiteLevel, blackLevel);
@@ -179,6 +179,12 @@ extern "C" int mfsr_accumulateSuperResFull(const uint16_t* dataIn, mfsr_float3* 
                            dimY, scale, strideOut, strideMask, mfsr_cfa_packed());
     return mfsr_launch_status("accumulateSuperResFull");
 }
+
+extern "C" int mfsr_accumulateSuperResFullN(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
+                                            mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
+                                            mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
+                                            mfsr_float3 blackLevel, int dimX, int dimY, int scale, int strideOut,
+                                            int strideMask, int accumulatorsUndefined, mfsr_stream_t stream);
 
 // Two frames onto the same accumulators in one call: what two successive
 // mfsr_accumulateSuperResFull calls compute (frame 0 then frame 1), with the accumulators read and
@@ -201,17 +207,49 @@ extern "C" int mfsr_accumulateSuperResFull2(const uint16_t* dataIn0, const uint1
     const uint16_t* raws[2] = {dataIn0, dataIn1};
     const mfsr_float4* masks[2] = {certaintyMask0, certaintyMask1};
     const mfsr_tex2d sh[2] = {shifts0, shifts1};
-    if (g_accumulate_fast == 2 && scale == 2 &&
-        mfsr_try_launch_accumulate2x_strip(2, raws, imgOut, totalWeights, masks, kernelParam, sh, whiteLevel, blackLevel, dimX,
-                                           dimY, strideOut, strideMask, stream) == 1)
-        return mfsr_launch_status("accumulateSuperResFull2(strip)");
-    if (g_accumulate_fast == 2 && scale == 4 &&
-        mfsr_try_launch_accumulate4x_tile(2, raws, imgOut, totalWeights, masks, kernelParam, sh, whiteLevel, blackLevel, dimX,
-                                          dimY, strideOut, strideMask, stream) == 1)
-        return mfsr_launch_status("accumulateSuperResFull2(x4 tile)");
-    rc = mfsr_accumulateSuperResFull(dataIn0, imgOut, totalWeights, certaintyMask0, kernelParam, shifts0, whiteLevel, blackLevel,
-                                     dimX, dimY, scale, strideOut, strideMask, stream);
-    if (rc) return rc;
-    return mfsr_accumulateSuperResFull(dataIn1, imgOut, totalWeights, certaintyMask1, kernelParam, shifts1, whiteLevel,
-                                       blackLevel, dimX, dimY, scale, strideOut, strideMask, stream);
+    return mfsr_accumulateSuperResFullN(2, raws, imgOut, totalWeights, masks, kernelParam, sh, whiteLevel, blackLevel, dimX, dimY,
+                                        scale, strideOut, strideMask, 0, stream);
 }
+
+// nFrames (1 or 2) frames in one call; accumulatorsUndefined != 0: the planes are overwritten as if
+// they had been zeroed before the call (the first launch of a burst: saves the memset and the read of
+// both planes -- 0 + x == x, so the result equals the zeroed-and-accumulated one bit for bit).
+extern "C" int mfsr_accumulateSuperResFullN(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
+                                            mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
+                                            mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
+                                            mfsr_float3 blackLevel, int dimX, int dimY, int scale, int strideOut,
+                                            int strideMask, int accumulatorsUndefined, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(nFrames >= 1 && nFrames <= 2 && dataIn && certaintyMask && shifts);
+    MFSR_REQUIRE(scale >= 1 && scale <= 8);
+    for (int n = 0; n < nFrames; n++) {
+        const int rc = check_superres_args(dataIn[n], imgOut, totalWeights, certaintyMask[n], kernelParam, shifts[n], dimX, dimY,
+                                           dimX * scale, strideOut, strideMask);
+        if (rc) return rc;
+    }
+    const int fresh = accumulatorsUndefined ? 1 : 0;
+    if (g_accumulate_fast == 2 && scale == 2) {
+        const int r = mfsr_try_launch_accumulate2x_strip(nFrames, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts,
+                                                         whiteLevel, blackLevel, dimX, dimY, strideOut, strideMask, fresh, stream);
+        if (r == 1) return mfsr_launch_status("accumulateSuperResFullN(strip)");
+        if (r < 0) return MFSR_E_INVALID;
+    }
+    if (g_accumulate_fast == 2 && scale == 4) {
+        const int r = mfsr_try_launch_accumulate4x_tile(nFrames, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts,
+                                                        whiteLevel, blackLevel, dimX, dimY, strideOut, strideMask, fresh, stream);
+        if (r == 1) return mfsr_launch_status("accumulateSuperResFullN(x4 tile)");
+        if (r < 0) return MFSR_E_INVALID;
+    }
+    if (fresh) {
+        const size_t bytes = (size_t)dimY * scale * strideOut;
+        MFSR_HIP_TRY(hipMemsetAsync(imgOut, 0, bytes, mfsr_s(stream)));
+        MFSR_HIP_TRY(hipMemsetAsync(totalWeights, 0, bytes, mfsr_s(stream)));
+    }
+    for (int n = 0; n < nFrames; n++) {
+        const int rc = mfsr_accumulateSuperResFull(dataIn[n], imgOut, totalWeights, certaintyMask[n], kernelParam, shifts[n],
+                                                   whiteLevel, blackLevel, dimX, dimY, scale, strideOut, strideMask, stream);
+        if (rc) return rc;
+    }
+    return MFSR_OK;
+}
+

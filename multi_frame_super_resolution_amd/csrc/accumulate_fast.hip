@@ -539,7 +539,7 @@ template <int CFA, int NF>
 __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     k_accumulate2xTile(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
                        Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked,
-                       int tilesX, int tilesY, int tilesPerXcd)
+                       int tilesX, int tilesY, int tilesPerXcd, int fresh)
 {
     // Optional XCD-aware tile order (tilesPerXcd > 0).  Workgroups are dealt round-robin to the 8 XCDs
     // (workgroup i -> XCD i & 7), each with its own L2; vertically adjacent tiles share a field-texel
@@ -610,7 +610,14 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     const size_t segByte = (size_t)bIdX * 3072;
     char* gP = (char*)imgOut + (size_t)Y * strideOut + segByte;
     char* gW = (char*)totalWeights + (size_t)Y * strideOut + segByte;
-    if (rowLive) {
+    if (rowLive && fresh) {
+        // first launch of a burst: the accumulators are defined to be zero and are not read at all
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            sAcc[ly][0][j * 64 + lx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            sAcc[ly][1][j * 64 + lx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    } else if (rowLive) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const size_t off = (size_t)(j * 64 + lx) * 16;
@@ -863,7 +870,7 @@ template <int CFA, int NF>
 __global__ void __launch_bounds__(256, 3)
     k_accumulate4xTile(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
                        Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked,
-                       int tilesX)
+                       int tilesX, int fresh)
 {
     const int bIdY = (int)blockIdx.x / tilesX, bIdX = (int)blockIdx.x - bIdY * tilesX;
     const int hrW = 4 * dimX, hrH = 4 * dimY;
@@ -926,14 +933,22 @@ __global__ void __launch_bounds__(256, 3)
     const size_t segByte = (size_t)bIdX * 6144 + (size_t)h * 3072;
     char* gP = (char*)imgOut + (size_t)Y * strideOut + segByte;
     char* gW = (char*)totalWeights + (size_t)Y * strideOut + segByte;
+    if (fresh) {
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const size_t off = (size_t)(j * 64 + lx) * 16;
-        if (segByte + off + 16 <= rowBytes) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gP + off),
-                                             (__attribute__((address_space(3))) void*)&sAcc[r][0][h * 192 + j * 64], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW + off),
-                                             (__attribute__((address_space(3))) void*)&sAcc[r][1][h * 192 + j * 64], 16, 0, 0);
+        for (int j = 0; j < 3; j++) {
+            sAcc[r][0][h * 192 + j * 64 + lx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            sAcc[r][1][h * 192 + j * 64 + lx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const size_t off = (size_t)(j * 64 + lx) * 16;
+            if (segByte + off + 16 <= rowBytes) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gP + off),
+                                                 (__attribute__((address_space(3))) void*)&sAcc[r][0][h * 192 + j * 64], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW + off),
+                                                 (__attribute__((address_space(3))) void*)&sAcc[r][1][h * 192 + j * 64], 16, 0, 0);
+            }
         }
     }
     __syncthreads();
@@ -1081,12 +1096,12 @@ bool tile_kernel_ok(mfsr_tex2d kp, mfsr_tex2d sh, int dimX, int dimY)
 
 template <int CFA, int NF>
 void launch_tile(dim3 grid, dim3 block, hipStream_t st, const TileFrames<NF>& fr, pix3* imgOut, pix3* tw, mfsr_tex2d kp,
-                 Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
+                 Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int fresh)
 {
     const int tilesX = (int)grid.x, tilesY = (int)grid.y;
     const int tilesPerXcd = g_strip_xcd_remap ? mfsr_cdiv(tilesX * tilesY, 8) : 0;
     hipLaunchKernelGGL((k_accumulate2xTile<CFA, NF>), dim3(tilesPerXcd ? 8 * tilesPerXcd : tilesX * tilesY), block, 0, st, fr,
-                       imgOut, tw, kp, glv, lv, dimX, dimY, strideOut, strideMask, cfaPacked, tilesX, tilesY, tilesPerXcd);
+                       imgOut, tw, kp, glv, lv, dimX, dimY, strideOut, strideMask, cfaPacked, tilesX, tilesY, tilesPerXcd, fresh);
 }
 
 template <int CFA, int NF>
@@ -1122,14 +1137,15 @@ void read_env_once()
 }  // namespace
 
 // Returns 1 if the fast kernels were launched for all `nFrames` (1 or 2) frames, 0 if the
-// configuration is not one they handle (caller falls back to the straight kernel), < 0 never.
+// configuration is not one they handle (caller falls back to the straight kernel), -1 if a memset of
+// the fresh-accumulator mode failed.
 // With two frames the LDS tile kernel fuses both in one pass over the accumulators; the other
 // geometries run frame after frame.
 int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
                                        mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
                                        mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
                                        mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
-                                       mfsr_stream_t stream)
+                                       int fresh, mfsr_stream_t stream)
 {
     read_env_once();
     if (nFrames < 1 || nFrames > 2) return 0;
@@ -1158,6 +1174,24 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
     const int cp = mfsr_cfa_packed();
     const bool pair = nFrames == 2 && tile_kernel_ok(kernelParam, shifts[0], dimX, dimY) &&
                       tile_kernel_ok(kernelParam, shifts[1], dimX, dimY);
+    // fresh accumulators ("as if zeroed", never read): the tile kernels write every row outside the top
+    // and bottom margin bands themselves, the bands are zeroed here; the other kernels get a full memset
+    const bool tileFirst = pair || (nFrames == 1 && tile_kernel_ok(kernelParam, shifts[0], dimX, dimY));
+    int tileFresh = 0;
+    if (fresh) {
+        if (tileFirst) {
+            tileFresh = 1;
+            const size_t band = (size_t)STRIP_MARGIN * strideOut;
+            for (int p2 = 0; p2 < 2; p2++) {
+                char* base = p2 ? (char*)totalWeights : (char*)imgOut;
+                if (hipMemsetAsync(base, 0, band, st) != hipSuccess) return -1;
+                if (hipMemsetAsync(base + (size_t)(hrH - STRIP_MARGIN) * strideOut, 0, band, st) != hipSuccess) return -1;
+            }
+        } else {
+            if (hipMemsetAsync(imgOut, 0, (size_t)hrH * strideOut, st) != hipSuccess) return -1;
+            if (hipMemsetAsync(totalWeights, 0, (size_t)hrH * strideOut, st) != hipSuccess) return -1;
+        }
+    }
     auto launch_margin = [&](int n) {
         const int M = STRIP_MARGIN;
         const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
@@ -1174,7 +1208,7 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
                 fr.f[n].shifts = shifts[n];                                                                            \
             }                                                                                                          \
             launch_tile<pack_cfa(a, b, c, d), 2>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY, strideOut, \
-                                                 strideMask, cp);                                                      \
+                                                 strideMask, cp, tileFresh);                                           \
             launch_margin(0);                                                                                          \
             launch_margin(1);                                                                                          \
         } else if (nFrames == 2) {                                                                                     \
@@ -1195,7 +1229,7 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
             fr.f[0].shifts = shifts[0];                                                                                \
             if (tile_kernel_ok(kernelParam, shifts[0], dimX, dimY))                                                    \
                 launch_tile<pack_cfa(a, b, c, d), 1>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY,    \
-                                                     strideOut, strideMask, cp);                                       \
+                                                     strideOut, strideMask, cp, tileFresh);                            \
             else                                                                                                       \
                 launch_strip_regs<pack_cfa(a, b, c, d), 1>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX,    \
                                                            dimY, strideOut, strideMask, cp);                           \
@@ -1220,7 +1254,7 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
                                       mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
                                       mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
                                       mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
-                                      mfsr_stream_t stream)
+                                      int fresh, mfsr_stream_t stream)
 {
     read_env_once();
     if (nFrames < 1 || nFrames > 2 || !g_strip_use_tile) return 0;
@@ -1251,6 +1285,14 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
     const int cp = mfsr_cfa_packed();
     const int tilesX = mfsr_cdiv(hrW, 512), tilesY = hrH / 2;
     const dim3 block(64, 4), grid(tilesX * tilesY);
+    if (fresh) {  // the top and bottom margin bands are the only rows the tile kernel does not write
+        const size_t band = (size_t)STRIP_MARGIN * strideOut;
+        for (int p2 = 0; p2 < 2; p2++) {
+            char* base = p2 ? (char*)totalWeights : (char*)imgOut;
+            if (hipMemsetAsync(base, 0, band, st) != hipSuccess) return -1;
+            if (hipMemsetAsync(base + (size_t)(hrH - STRIP_MARGIN) * strideOut, 0, band, st) != hipSuccess) return -1;
+        }
+    }
     auto launch_margin = [&](int n) {
         const int M = STRIP_MARGIN;
         const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
@@ -1267,7 +1309,7 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
                 fr.f[n].shifts = shifts[n];                                                                            \
             }                                                                                                          \
             hipLaunchKernelGGL((k_accumulate4xTile<pack_cfa(a, b, c, d), 2>), grid, block, 0, st, fr, pI, pT, kernelParam, \
-                               glv, lv, dimX, dimY, strideOut, strideMask, cp, tilesX);                                \
+                               glv, lv, dimX, dimY, strideOut, strideMask, cp, tilesX, fresh ? 1 : 0);                 \
             launch_margin(0);                                                                                          \
             launch_margin(1);                                                                                          \
         } else {                                                                                                       \
@@ -1276,7 +1318,7 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
             fr.f[0].mask = (const float4*)certaintyMask[0];                                                            \
             fr.f[0].shifts = shifts[0];                                                                                \
             hipLaunchKernelGGL((k_accumulate4xTile<pack_cfa(a, b, c, d), 1>), grid, block, 0, st, fr, pI, pT, kernelParam, \
-                               glv, lv, dimX, dimY, strideOut, strideMask, cp, tilesX);                                \
+                               glv, lv, dimX, dimY, strideOut, strideMask, cp, tilesX, fresh ? 1 : 0);                 \
             launch_margin(0);                                                                                          \
         }                                                                                                              \
         return 1;

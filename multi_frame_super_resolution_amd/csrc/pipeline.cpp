@@ -218,6 +218,11 @@ struct mfsr_burst {
         mfsr_float3 *imgOut, *totalWeights;
     } pend;
     int nFramesTimed;
+    // mfsr_burst_begin: these accumulators are to be overwritten by the first fuse instead of zeroed
+    struct Fresh {
+        bool has;
+        mfsr_float3 *imgOut, *totalWeights;
+    } fresh;
     // ring + asynchronous fuse (cfg.asyncFuse)
     int frameCounter;
     hipStream_t fuseStream;             // high priority, non-blocking; null without asyncFuse
@@ -236,7 +241,7 @@ struct mfsr_burst {
         if (rc_ != MFSR_OK) return rc_; \
     } while (0)
 
-static int flush_pending(mfsr_burst* b, mfsr_stream_t stream);
+static int flush_pending(mfsr_burst* b, mfsr_stream_t stream, bool materializeFresh = true);
 
 
 extern "C" int mfsr_config_default(mfsr_config* cfg, int width, int height, int frames, int scale, int mono)
@@ -330,6 +335,7 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     b->flowCur = &b->L.flowBuf[0];
     b->maskCur = &b->L.maskBuf[0];
     b->pend.has = false;
+    b->fresh.has = false;
     b->nFramesTimed = 0;
     b->timing = false;
     b->nEvents = 0;
@@ -441,7 +447,7 @@ static int prepare_frame(mfsr_burst* b, const uint16_t* raw, Img& half, Img* pyr
 extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, mfsr_stream_t stream)
 {
     MFSR_REQUIRE(b && rawRef);
-    TRY(flush_pending(b, stream));  // a frame still waiting belongs to the previous reference
+    TRY(flush_pending(b, stream, false));  // a frame still waiting belongs to the previous reference
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
     TRY(prepare_frame(b, rawRef, L.refHalf, L.refPyr, stream));
@@ -557,13 +563,16 @@ static int accumulate_frames(mfsr_burst* b, int n, int slot0, int slot1, const u
         if (!b->evStop[i]) MFSR_HIP_TRY(hipEventCreate(&b->evStop[i]));
         MFSR_HIP_TRY(hipEventRecord(b->evStart[i], mfsr_s(stream)));
     }
-    if (n == 2)
-        TRY(mfsr_accumulateSuperResFull2(raw0, raw1, imgOut, totalWeights, (const mfsr_float4*)mask0->ptr,
-                                         (const mfsr_float4*)mask1->ptr, as_tex(L.kparam4), as_tex(*flow0), as_tex(*flow1),
-                                         white, black, L.W, L.H, c.scale, strideOut, mask0->pitch, stream));
-    else
-        TRY(mfsr_accumulateSuperResFull(raw0, imgOut, totalWeights, (const mfsr_float4*)mask0->ptr, as_tex(L.kparam4),
-                                        as_tex(*flow0), white, black, L.W, L.H, c.scale, strideOut, mask0->pitch, stream));
+    {
+        const uint16_t* raws[2] = {raw0, raw1};
+        const mfsr_float4* masks[2] = {(const mfsr_float4*)mask0->ptr, n == 2 ? (const mfsr_float4*)mask1->ptr : nullptr};
+        const mfsr_tex2d flows[2] = {as_tex(*flow0), n == 2 ? as_tex(*flow1) : as_tex(*flow0)};
+        // the first fuse after mfsr_burst_begin overwrites the accumulators (they are not zeroed or read)
+        const int freshNow = b->fresh.has && b->fresh.imgOut == imgOut && b->fresh.totalWeights == totalWeights;
+        b->fresh.has = false;
+        TRY(mfsr_accumulateSuperResFullN(n, raws, imgOut, totalWeights, masks, as_tex(L.kparam4), flows, white, black, L.W, L.H,
+                                         c.scale, strideOut, mask0->pitch, freshNow, stream));
+    }
     if (timed) {
         MFSR_HIP_TRY(hipEventRecord(b->evStop[b->nEvents], mfsr_s(stream)));
         b->nEvents++;
@@ -593,8 +602,15 @@ static int join_fuse(mfsr_burst* b, mfsr_stream_t stream)
 }
 
 // fuse a frame still waiting for its partner, then join: afterwards the caller's stream sees every frame
-static int flush_pending(mfsr_burst* b, mfsr_stream_t stream)
+static int flush_pending(mfsr_burst* b, mfsr_stream_t stream, bool materializeFresh)
 {
+    if (materializeFresh && b->fresh.has && !b->pend.has) {
+        // mfsr_burst_begin with no frame fused since: the accumulators must read as zero
+        const size_t bytes = (size_t)12 * b->L.hrW * b->L.hrH;
+        MFSR_HIP_TRY(hipMemsetAsync(b->fresh.imgOut, 0, bytes, mfsr_s(stream)));
+        MFSR_HIP_TRY(hipMemsetAsync(b->fresh.totalWeights, 0, bytes, mfsr_s(stream)));
+        b->fresh.has = false;
+    }
     if (b->pend.has) {
         mfsr_burst::Pending p = b->pend;
         b->pend.has = false;
@@ -684,6 +700,16 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
         return MFSR_OK;
     }
     return accumulate_frames(b, 1, slot, -1, raw, nullptr, flow, nullptr, mask, nullptr, imgOut, totalWeights, stream);
+}
+
+extern "C" int mfsr_burst_begin(mfsr_burst* b, mfsr_float3* imgOut, mfsr_float3* totalWeights, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && imgOut && totalWeights);
+    TRY(flush_pending(b, stream));  // whatever was still waiting belongs to the previous burst
+    b->fresh.has = true;
+    b->fresh.imgOut = imgOut;
+    b->fresh.totalWeights = totalWeights;
+    return MFSR_OK;
 }
 
 extern "C" int mfsr_burst_flush(mfsr_burst* b, mfsr_stream_t stream)

@@ -65,7 +65,7 @@ def accumulate_local(pipe, frames, rank: int, world: int, n_frames: Optional[int
     rank of a large burst keeps resident)."""
     ref = pipe.cfg.reference
     n = len(frames) if n_frames is None else n_frames
-    pipe.reset_accumulators()
+    getattr(pipe, "begin_burst", pipe.reset_accumulators)()   # accumulators := 0 (lazily, where the pipe can)
     pipe.set_reference(frames[ref])
     mine = frames_of_rank(n, rank, world)
     for k in mine:

@@ -84,6 +84,12 @@ class BurstPipeline:
         self._img_out.zero_()
         self._total_weights.zero_()
 
+    def begin_burst(self):
+        """Start a burst without zeroing: the first warp+fuse launch overwrites the accumulators
+        (mfsr_burst_begin).  Equivalent to reset_accumulators() for every reader (flush zeroes them if no
+        frame was added)."""
+        self.L.burst_begin(self._h, self._img_out.data_ptr(), self._total_weights.data_ptr(), self._stream())
+
     def set_reference(self, raw: torch.Tensor):
         self._check_raw(raw)
         self.L.burst_set_reference(self._h, raw.data_ptr(), self._stream())
@@ -108,7 +114,7 @@ class BurstPipeline:
 
     def process(self, frames: Sequence[torch.Tensor], frame_ids: Optional[Iterable[int]] = None):
         """Whole burst on this device: reference products, every frame, finish."""
-        self.reset_accumulators()
+        self.begin_burst()
         ref = self.cfg.reference
         self.set_reference(frames[ref])
         ids = range(len(frames)) if frame_ids is None else frame_ids

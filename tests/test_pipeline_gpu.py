@@ -273,3 +273,34 @@ def test_degenerate_bursts_finish_with_finite_output(kind):
         # debayer of the fallback image overshoots a little, exactly as in the oracle); it stays bounded
         assert float(out.min()) > -1.0 and float(out.max()) < 32.0
         pipe.close()
+
+
+@pytest.mark.parametrize("scale,mono", [(2, False), (4, False), (2, True)])
+def test_begin_burst_equals_zeroed_accumulators(scale, mono):
+    """mfsr_burst_begin: the first warp+fuse launch overwrites the accumulators instead of adding to
+    zeroed ones -- bit-identical, also when they held garbage, for an odd frame count, and when no frame
+    follows (then they read as zero)."""
+    import torch
+    from multi_frame_super_resolution_amd import synth
+    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, default_config
+    dev = torch.device("cuda:0")
+    W, H, N = 328, 264, 3
+    frames, _, _ = synth.make_burst(W, H, N, scale=scale, mono=mono, seed=17, device=dev)
+    cfg = default_config(W, H, N, scale=scale, mono=mono)
+    pipe = BurstPipeline(cfg, dev)
+    pipe.reset_accumulators()
+    pipe.set_reference(frames[0])
+    for k in range(N):
+        pipe.add_frame(frames[k], k == 0)
+    ref_acc, ref_w = pipe.img_out.clone(), pipe.total_weights.clone()
+    pipe._img_out.fill_(float("nan"))            # garbage that must never be read
+    pipe._total_weights.fill_(1e30)
+    pipe.begin_burst()
+    pipe.set_reference(frames[0])
+    for k in range(N):
+        pipe.add_frame(frames[k], k == 0)
+    assert torch.equal(pipe.img_out, ref_acc) and torch.equal(pipe.total_weights, ref_w)
+    pipe._img_out.fill_(7.0)
+    pipe.begin_burst()
+    assert float(pipe.img_out.abs().max()) == 0.0 and float(pipe.total_weights.abs().max()) == 0.0
+    pipe.close()
