@@ -15,11 +15,17 @@ xGMI, each rank finishes its stripe, rank 0 gathers the u16 result
 at 16 frames and shards it instead.
 
 Also reported on the same JSON line:
-  roofline     : the warp+fuse kernel (accumulateSuperResFull), HIP-event timed
-                 around every launch inside the timed region, vs the 8 TB/s HBM peak;
+  roofline     : the warp+fuse launches (accumulateSuperResFullN: two frames per launch with frame
+                 pairing), HIP-event timed around every launch inside the timed region, algorithmic
+                 bytes = per-frame figure x frames per launch, vs the 8 TB/s HBM peak;
   cpu_baseline : the CPU oracle pipeline ("port" of the same algorithm; the
                  reference's own CPU path is third-party OpenCV BTVL1, absent here)
-                 timed on the host cores on a bounded sample of the same workload.
+                 timed on the host cores on a bounded sample of the same workload, plus the parity of
+                 the HIP path against it on that sample (PSNR, fractions off by more than 1 LSB).
+
+Other modes (not the contract's `value`): --h2d (frames streamed from pinned host memory), --no-pair,
+--async-fuse, --unfused, --workload {1080p5_gray_x2, 4k16_rggb_x4, 8k8_rggb_x2}, and
+MFSR_DIST_BACKEND=gloo (functional rehearsal of the multi-rank schedule on fewer GPUs than ranks).
 """
 from __future__ import annotations
 
