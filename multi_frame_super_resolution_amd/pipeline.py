@@ -122,6 +122,21 @@ class BurstPipeline:
             self.add_frame(frames[k], k == ref)
         return self.finish()
 
+    def process_stream(self, frames: Sequence[torch.Tensor], radius: int = 1):
+        """Sliding-window ("temporal area radius", reference multi_frame_sr.cpp:182) use of the burst path:
+        output t fuses frames [t-radius, t+radius] (clipped to the stream) with frame t as the reference.
+        Yields (t, u16 HR image) -- the image is the pipeline's output buffer, valid until the next step.
+        cfg.frames only sizes nothing here: any window length works with one context."""
+        n = len(frames)
+        for t in range(n):
+            lo, hi = max(0, t - radius), min(n - 1, t + radius)
+            self.begin_burst()
+            self.set_reference(frames[t])
+            for k in range(lo, hi + 1):
+                self.add_frame(frames[k], k == t)
+            _, out16 = self.finish(want_float=False, want_u16=True)
+            yield t, out16
+
     def debug_views(self):
         """(flow, mask, kernel_param, tracking) descriptors of the last add_frame."""
         t = [capi.Tex2D() for _ in range(4)]

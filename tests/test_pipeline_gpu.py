@@ -304,3 +304,30 @@ def test_begin_burst_equals_zeroed_accumulators(scale, mono):
     pipe.begin_burst()
     assert float(pipe.img_out.abs().max()) == 0.0 and float(pipe.total_weights.abs().max()) == 0.0
     pipe.close()
+
+
+@pytest.mark.parametrize("scale", [1, 2])
+def test_sliding_window_stream_equals_bursts(scale):
+    """process_stream (sliding window over a frame stream, also the x1
+    denoise-merge scale) gives, for every t, exactly the burst of its window with frame t as reference."""
+    import torch
+    from multi_frame_super_resolution_amd import synth
+    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, default_config
+    dev = torch.device("cuda:0")
+    W, H, N, R = 256, 192, 5, 1
+    frames, _, _ = synth.make_burst(W, H, N, scale=scale, seed=23, device=dev, max_shift=2.0)
+    cfg = default_config(W, H, 2 * R + 1, scale=scale)
+    pipe = BurstPipeline(cfg, dev)
+    stream = {t: o.clone() for t, o in pipe.process_stream(frames, radius=R)}
+    assert sorted(stream) == list(range(N))
+    ref = BurstPipeline(cfg, dev)
+    for t in range(N):
+        lo, hi = max(0, t - R), min(N - 1, t + R)
+        window = frames[lo:hi + 1]
+        ref.cfg.reference = t - lo
+        _, o16 = ref.process(window)
+        assert torch.equal(o16, stream[t]), f"t={t}"
+    # the middle outputs really fuse three different frames
+    assert not torch.equal(stream[1], stream[2])
+    pipe.close()
+    ref.close()
