@@ -42,6 +42,10 @@ static bool read_file(const std::string& path, std::vector<uint8_t>& out)
     if (!f) return false;
     fseek(f, 0, SEEK_END);
     long n = ftell(f);
+    if (n < 0 || n > (1L << 30)) {  // unseekable, or nothing this tool reads is a gigabyte
+        fclose(f);
+        return false;
+    }
     fseek(f, 0, SEEK_SET);
     out.resize(n);
     bool ok = fread(out.data(), 1, n, f) == (size_t)n;
@@ -63,6 +67,9 @@ static bool read_png(const std::string& path, Image8& img)
         const uint8_t* data = &buf[pos + 8];
         if (pos + 12 + len > buf.size()) return false;
         if (!memcmp(type, "IHDR", 4)) {
+            if (len < 13) return false;
+            const uint32_t uw = be32(data), uh = be32(data + 4);
+            if (uw == 0 || uh == 0 || uw > 65536 || uh > 65536) return false;  // also keeps (stride+1)*h far from overflow
             w = be32(data);
             h = be32(data + 4);
             depth = data[8];
@@ -75,7 +82,7 @@ static bool read_png(const std::string& path, Image8& img)
         }
         pos += 12 + len;
     }
-    if (depth != 8 || interlace != 0) return false;
+    if (w <= 0 || h <= 0 || depth != 8 || interlace != 0) return false;
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 6 ? 4 : ctype == 4 ? 2 : 0;
     if (!ch) return false;
     const size_t stride = (size_t)w * ch;

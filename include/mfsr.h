@@ -306,6 +306,41 @@ int mfsr_finishFused(const mfsr_float3* finalImg, const mfsr_float3* weight, int
                      int outPitch, uint16_t* out16, int width, int height, float threshold, int applyGamma,
                      float maxOut, mfsr_stream_t stream);
 
+/* ---- global pre-alignment.  The reference has the slot -- `class PreAlignment`,
+ *      boxFilterNPP.cpp:102-166; baseShift / baseRotation of kernel.cu:265,324 and opticalFlow.cu:48 -- but no finished
+ *      estimator (test_opencv/main.cpp:861-1194 returns nothing).  Model fixed by those kernels: reference pixel p maps
+ *      to moved pixel q = c + R(rotation) * (p - c - shift), c = (width/2, height/2).  The estimator is the build's own
+ *      (csrc/prealign.hip): exhaustive coarse-to-fine search on 2x2-mean pyramids, integer scores, angles on a 1/16
+ *      degree grid; no host round trip, the result stays in device memory. ---------------------------------------- */
+typedef struct {
+    float shiftX, shiftY;   /* base shift in pixels of the image the pyramids were built from */
+    float rotation;         /* base rotation in radians (= angleIndex * pi/2880) */
+    float cosRotation, sinRotation; /* cosf/sinf(rotation) of the host's libm */
+    int32_t angleIndex, tx, ty, level; /* raw search result: angle in 1/16 degree, shift at pyramid level `level` */
+    int32_t reserved[3];
+} mfsr_prealign;
+/* device bytes of one image's search pyramid / of the search workspace (trig table, scores, per-level state) */
+size_t mfsr_preAlign_pyramid_bytes(int width, int height);
+size_t mfsr_preAlign_workspace_bytes(float maxAngleDeg);
+/* uploads the trig table for |angle| <= maxAngleDeg into the workspace (once per workspace) */
+int mfsr_preAlign_init(void* workspace, float maxAngleDeg, mfsr_stream_t stream);
+/* 2x2-mean pyramid of img (float, pitched) down to a long side <= 64, quantised to 8 bit */
+int mfsr_preAlignPyramid(const float* img, int width, int height, int pitch, void* pyramid, mfsr_stream_t stream);
+/* search: *result (DEVICE memory) := base shift / rotation of the moved image against the reference image */
+int mfsr_preAlign(const void* refPyramid, const void* movedPyramid, int width, int height, float maxAngleDeg,
+                  void* workspace, mfsr_prealign* result, mfsr_stream_t stream);
+int mfsr_preAlign_identity(mfsr_prealign* result, mfsr_stream_t stream);
+/* mfsr_trackTilesFused with B2's baseShift / baseRotation taken from *base (device; NULL = none); the base shift is
+ * multiplied by baseInvScale (1 / down-sampling factor of this pyramid level) */
+int mfsr_trackTilesFusedBase(const float* refImg, const float* movedImg, const mfsr_float2* preShift, int preShiftPitch,
+                             mfsr_float2* coordinates, int coordinatesPitch, int imgWidth, int imgHeight, int imgPitch,
+                             int maxShift, int tileSize, int tileCountX, int tileCountY, float threshold,
+                             const float* refSquaredSums, const mfsr_prealign* base, float baseInvScale,
+                             mfsr_stream_t stream);
+/* mfsr_CreateFlowFieldFromTiles (opticalFlow.cu:48) with baseShift / baseRotation taken from *base (device) */
+int mfsr_CreateFlowFieldFromTilesBase(mfsr_float2* outImg, mfsr_tex2d texObjShiftXY, int imgWidth, int imgHeight,
+                                      int imgPitch, const mfsr_prealign* base, mfsr_stream_t stream);
+
 /* ---- burst pipeline (the L3 driver the reference lacks; mirrors the CLI
  *      contract of finalProject/Project/multi_frame_sr.cpp:122-210) ---------- */
 typedef struct {
@@ -340,7 +375,10 @@ typedef struct {
     int32_t pairFrames;      /* 1: add_frame fuses frames two at a time (see mfsr_burst_add_frame) */
     int32_t asyncFuse;       /* 1: the warp+fuse launches run on a stream owned by the burst, concurrently with the
                                 alignment of the following frames on the caller's stream (see mfsr_burst_add_frame) */
-    int32_t reserved[5];
+    int32_t preAlign;        /* 1: estimate a global base shift + rotation per moved frame (mfsr_preAlign) and feed it to
+                                the tile tracker and the flow field (baseShift / baseRotation of kernel.cu:324, opticalFlow.cu:48) */
+    float preAlignMaxAngle;  /* search range of the base rotation in degrees (default 20) */
+    int32_t reserved[3];
 } mfsr_config;
 
 typedef struct mfsr_burst mfsr_burst;
@@ -396,6 +434,8 @@ int mfsr_burst_timing_read(mfsr_burst* b, double* totalMs, int* launches, int* f
  * for tests: returns device pointers valid until the next add_frame */
 int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2d* mask, mfsr_tex2d* kernelParam,
                            mfsr_tex2d* tracking);
+/* global pre-alignment of the last add_frame (cfg.preAlign), copied to HOST memory; synchronises the stream */
+int mfsr_burst_prealign_result(mfsr_burst* b, mfsr_prealign* hostOut, mfsr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,14 @@ class Tex2D(ctypes.Structure):
                 ("height", ctypes.c_int32)]
 
 
+class PreAlign(ctypes.Structure):
+    """mfsr_prealign (include/mfsr.h)."""
+
+    _fields_ = [("shiftX", ctypes.c_float), ("shiftY", ctypes.c_float), ("rotation", ctypes.c_float),
+                ("cosRotation", ctypes.c_float), ("sinRotation", ctypes.c_float), ("angleIndex", ctypes.c_int32),
+                ("tx", ctypes.c_int32), ("ty", ctypes.c_int32), ("level", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+
+
 class Config(ctypes.Structure):
     """mfsr_config (include/mfsr.h)."""
 
@@ -58,7 +66,8 @@ class Config(ctypes.Structure):
         ("Dth", ctypes.c_float), ("Dtr", ctypes.c_float), ("kDetail", ctypes.c_float), ("kDenoise", ctypes.c_float),
         ("kStretch", ctypes.c_float), ("kShrink", ctypes.c_float),
         ("weightThreshold", ctypes.c_float), ("applyGamma", ctypes.c_int32), ("fused", ctypes.c_int32),
-        ("pairFrames", ctypes.c_int32), ("asyncFuse", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5),
+        ("pairFrames", ctypes.c_int32), ("asyncFuse", ctypes.c_int32),
+        ("preAlign", ctypes.c_int32), ("preAlignMaxAngle", ctypes.c_float), ("reserved", ctypes.c_int32 * 3),
     ]
 
 

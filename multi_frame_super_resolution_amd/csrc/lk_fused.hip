@@ -241,7 +241,10 @@ extern "C" int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_
     MFSR_REQUIRE((long long)pitchShift >= 8LL * width && (pitchShift & 7) == 0 && ((uintptr_t)shiftsIn & 7) == 0 &&
                  ((uintptr_t)shiftsOut & 7) == 0);
     const int h = halfWindowSize;
-    const int TX = (width >= 48 + 2 * h + 4 && h <= 7) ? 48 : 32;
+    // TX is a template parameter of the kernel: 48 only for the half-window sizes that have a <h,48>
+    // instantiation below (1..7); every other size runs the generic <0,32> kernel
+    const bool hasWide = h >= 1 && h <= 7;
+    const int TX = (hasWide && width >= 48 + 2 * h + 4) ? 48 : 32;
     const int BW = TX + 2 * h + 4, BH = LK_TY + 2 * h + 4, AW = TX + 2 * h, AH = LK_TY + 2 * h;
     const size_t lds = sizeof(float) * ((size_t)2 * BW * BH + (size_t)5 * AW * AH + (size_t)5 * TX * AH);
     if (lds > 160 * 1024) return MFSR_E_UNSUPPORTED;
@@ -274,8 +277,12 @@ extern "C" int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_
         LK_CASE(3)
         LK_CASE(4)
         LK_CASE(5)
+        LK_CASE(6)
         LK_CASE(7)
-        default: LK_LAUNCH(0, 32); break;
+        default:
+            if (TX != 32) return MFSR_E_UNSUPPORTED;  // unreachable: hasWide covers exactly the cases above
+            LK_LAUNCH(0, 32);
+            break;
     }
 #undef LK_CASE
 #undef LK_LAUNCH

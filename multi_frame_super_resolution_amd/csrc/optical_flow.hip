@@ -73,6 +73,43 @@ extern "C" int mfsr_CreateFlowFieldFromTiles(mfsr_float2* outImg, mfsr_tex2d tex
     return mfsr_launch_status("CreateFlowFieldFromTiles");
 }
 
+// D1 with the base shift / rotation read from device memory (result of mfsr_preAlign): same arithmetic, cos/sin of the
+// base rotation from the host-built table (= cosf/sinf(rotation) of the host's libm, what the CPU oracle evaluates)
+__global__ void __launch_bounds__(256)
+    k_CreateFlowFieldFromTilesBase(float2* __restrict__ outImg, mfsr_tex2d texShift, int imgWidth, int imgHeight, int imgPitch,
+                                   const mfsr_prealign* __restrict__ base)
+{
+    const int pxX = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pxY = blockIdx.y * blockDim.y + threadIdx.y;
+    if (pxX >= imgWidth || pxY >= imgHeight) return;
+    const float cf = base->cosRotation, sf = base->sinRotation;
+    const float bx = base->shiftX, by = base->shiftY;
+    float2 shift;
+    shift.x = cf * -bx - sf * -by;
+    shift.y = sf * -bx + cf * -by;
+    const float patchCenterX = (float)(pxX - imgWidth / 2);
+    const float patchCenterY = (float)(pxY - imgHeight / 2);
+    shift.x += cf * patchCenterX - sf * patchCenterY - patchCenterX;
+    shift.y += sf * patchCenterX + cf * patchCenterY - patchCenterY;
+    const float2 shiftPatch =
+        tex2<ADDR_CLAMP>(texShift, ((float)pxX + 0.5f) / (float)imgWidth, ((float)pxY + 0.5f) / (float)imgHeight);
+    shift.x += shiftPatch.x;
+    shift.y += shiftPatch.y;
+    row_ptr(outImg, imgPitch, pxY)[pxX] = shift;
+}
+
+extern "C" int mfsr_CreateFlowFieldFromTilesBase(mfsr_float2* outImg, mfsr_tex2d texObjShiftXY, int imgWidth, int imgHeight,
+                                                 int imgPitch, const mfsr_prealign* base, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(outImg && base && imgWidth > 0 && imgHeight > 0);
+    MFSR_REQUIRE((long long)imgPitch >= 8LL * imgWidth && (imgPitch & 7) == 0 && ((uintptr_t)outImg & 7) == 0);
+    MFSR_REQUIRE(mfsr_tex_ok(texObjShiftXY, 8) && ((uintptr_t)texObjShiftXY.ptr & 7) == 0 && (texObjShiftXY.pitch & 7) == 0);
+    dim3 block(64, 4), grid(mfsr_cdiv(imgWidth, 64), mfsr_cdiv(imgHeight, 4));
+    hipLaunchKernelGGL(k_CreateFlowFieldFromTilesBase, grid, block, 0, mfsr_s(stream), (float2*)outImg, texObjShiftXY, imgWidth,
+                       imgHeight, imgPitch, base);
+    return mfsr_launch_status("CreateFlowFieldFromTilesBase");
+}
+
 // ---- D3/E1: 5-point derivatives (opticalFlow.cu:97-185) -----------------------
 __device__ __forceinline__ float deriv5(const mfsr_tex2d& t, float x, float y, float dx, float dy)
 {

@@ -67,6 +67,9 @@ struct Layout {
     Img warped, Ix, Iy, It, rawf;
     float *refTiles, *movTiles, *cc, *boxX, *boxY, *sqsum, *dist;
     float* refSq[kMaxLevels];  // fused tracker: sum(ref^2) per tile and level, taken once per reference
+    // global pre-alignment (cfg.preAlign): search pyramids of the reference and the moved frame, workspace, result
+    void *preRefPyr, *preMovPyr, *preWork;
+    mfsr_prealign* preResult;
     size_t total;
 };
 
@@ -112,9 +115,20 @@ int validate(const mfsr_config* c)
         if (l > 0) MFSR_REQUIRE(c->levelFactor[l] < c->levelFactor[l - 1]);
         MFSR_REQUIRE(c->tileSize[l] >= 4 && c->tileSize[l] <= 128 && c->maxShift[l] >= 1 && c->maxShift[l] <= 15);
         MFSR_REQUIRE(c->tileSize[l] > 2 * c->maxShift[l]);
+        if (c->fused) {
+            // LDS need of one tile in mfsr_trackTilesFused (template + patch + row sums + distance image): fail at
+            // create, not at the first add_frame (tileSize >~ 90); cfg.fused = 0 serves larger tiles
+            const long long T = c->tileSize[l], S = c->maxShift[l], Lt = T + 2 * S, R = 2 * S + 1;
+            if (4 * (T * T + Lt * (Lt + 1) + 1 + Lt * R + R * R + 4) > 64 * 1024) {
+                fprintf(stderr, "mfsr: tileSize %d / maxShift %d exceeds the fused tile tracker's LDS budget (use cfg.fused = 0)\n",
+                        (int)T, (int)S);
+                return MFSR_E_UNSUPPORTED;
+            }
+        }
     }
     MFSR_REQUIRE(c->lkIterations >= 0 && c->lkHalfWindow >= 0 && c->lkHalfWindow <= 15);
     MFSR_REQUIRE(c->maxVal > 0);
+    if (c->preAlign) MFSR_REQUIRE(c->preAlignMaxAngle >= 0.0f && c->preAlignMaxAngle <= 45.0f);
     return MFSR_OK;
 }
 
@@ -181,6 +195,13 @@ void make_layout(const mfsr_config* c, char* base, Layout* L)
         L->boxY = (float*)b.take(maxTileFloats * 4);
         L->sqsum = (float*)b.take(maxTiles * 4);
         L->dist = (float*)b.take(maxDist * 4);
+    }
+    if (c->preAlign) {
+        const size_t pb = mfsr_preAlign_pyramid_bytes(L->tw, L->th);
+        L->preRefPyr = b.take(pb);
+        L->preMovPyr = b.take(pb);
+        L->preWork = b.take(mfsr_preAlign_workspace_bytes(c->preAlignMaxAngle));
+        L->preResult = (mfsr_prealign*)b.take(sizeof(mfsr_prealign));
     }
     L->total = align_up(b.off, 256);
 }
@@ -294,6 +315,8 @@ extern "C" int mfsr_config_default(mfsr_config* cfg, int width, int height, int 
     cfg->applyGamma = 0;
     cfg->fused = 1;
     cfg->pairFrames = 1;
+    cfg->preAlign = 0;   // opt-in: bursts with rotations / shifts beyond the tile tracker's reach (the bundled "city" burst)
+    cfg->preAlignMaxAngle = 20.0f;
     cfg->asyncFuse = 0;  // +5 % burst throughput, -17 % on the fuse launches it overlaps: opt-in
     return MFSR_OK;
 }
@@ -458,6 +481,11 @@ extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, m
                                      L.tcx[l], L.tcy[l], stream));
         }
 
+    if (c.preAlign) {
+        TRY(mfsr_preAlign_init(L.preWork, c.preAlignMaxAngle, stream));
+        TRY(mfsr_preAlignPyramid((const float*)L.refPyr[0].ptr, L.tw, L.th, L.refPyr[0].pitch, L.preRefPyr, stream));
+    }
+
     // E: kernel shape field from the reference tracking image
     if (c.fused) {
         TRY(mfsr_structureTensorFused((const float*)L.refPyr[0].ptr, L.refPyr[0].pitch, (mfsr_float3*)L.tensor.ptr,
@@ -493,7 +521,7 @@ extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, m
 }
 
 // B: coarse -> fine tile tracking of the moved pyramid against the reference
-static int track_tiles(mfsr_burst* b, mfsr_stream_t stream)
+static int track_tiles(mfsr_burst* b, const mfsr_prealign* hostBase, mfsr_stream_t stream)
 {
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
@@ -512,9 +540,10 @@ static int track_tiles(mfsr_burst* b, mfsr_stream_t stream)
             pre = (const mfsr_float2*)L.pre[l].ptr;
         }
         if (c.fused) {
-            TRY(mfsr_trackTilesFused((const float*)ref.ptr, (const float*)mov.ptr, pre, L.pre[l].pitch,
-                                     (mfsr_float2*)L.shifts[l].ptr, L.shifts[l].pitch, ref.w, ref.h, ref.pitch, S, T,
-                                     L.tcx[l], L.tcy[l], c.minimumThreshold, L.refSq[l], stream));
+            TRY(mfsr_trackTilesFusedBase((const float*)ref.ptr, (const float*)mov.ptr, pre, L.pre[l].pitch,
+                                         (mfsr_float2*)L.shifts[l].ptr, L.shifts[l].pitch, ref.w, ref.h, ref.pitch, S, T,
+                                         L.tcx[l], L.tcy[l], c.minimumThreshold, L.refSq[l],
+                                         c.preAlign ? L.preResult : nullptr, 1.0f / (float)c.levelFactor[l], stream));
         } else {
             if (!pre) {
                 MFSR_HIP_TRY(hipMemsetAsync(L.pre[l].ptr, 0, (size_t)L.pre[l].pitch * L.pre[l].h, mfsr_s(stream)));
@@ -522,8 +551,16 @@ static int track_tiles(mfsr_burst* b, mfsr_stream_t stream)
             }
             TRY(mfsr_convertToTilesOverlapBorder((const float*)ref.ptr, L.refTiles, ref.w, ref.h, ref.pitch, S, T, L.tcx[l],
                                                  L.tcy[l], zero2, 0.0f, stream));
+            mfsr_float2 base = zero2;
+            float rot = 0.0f;
+            if (hostBase) {
+                const float inv = 1.0f / (float)c.levelFactor[l];
+                base.x = hostBase->shiftX * inv;
+                base.y = hostBase->shiftY * inv;
+                rot = hostBase->rotation;
+            }
             TRY(mfsr_convertToTilesOverlapPreShift((const float*)mov.ptr, L.movTiles, pre, L.pre[l].pitch, mov.w, mov.h,
-                                                   mov.pitch, S, T, L.tcx[l], L.tcy[l], zero2, 0.0f, stream));
+                                                   mov.pitch, S, T, L.tcx[l], L.tcy[l], base, rot, stream));
             TRY(mfsr_crossCorrelateTiles(L.refTiles, L.movTiles, L.cc, S, T, tiles, stream));
             TRY(mfsr_squaredSum(L.refTiles, L.sqsum, S, T, tiles, stream));
             TRY(mfsr_boxFilterWithBorderX(L.movTiles, L.boxX, S, T, tiles, stream));
@@ -569,6 +606,12 @@ static int accumulate_frames(mfsr_burst* b, int n, int slot0, int slot1, const u
         const mfsr_tex2d flows[2] = {as_tex(*flow0), n == 2 ? as_tex(*flow1) : as_tex(*flow0)};
         // the first fuse after mfsr_burst_begin overwrites the accumulators (they are not zeroed or read)
         const int freshNow = b->fresh.has && b->fresh.imgOut == imgOut && b->fresh.totalWeights == totalWeights;
+        if (b->fresh.has && !freshNow) {
+            // begin(A, W) followed by a fuse into other accumulators: A and W still owe their zeroes
+            const size_t bytes = (size_t)12 * L.hrW * L.hrH;
+            MFSR_HIP_TRY(hipMemsetAsync(b->fresh.imgOut, 0, bytes, mfsr_s(stream)));
+            MFSR_HIP_TRY(hipMemsetAsync(b->fresh.totalWeights, 0, bytes, mfsr_s(stream)));
+        }
         b->fresh.has = false;
         TRY(mfsr_accumulateSuperResFullN(n, raws, imgOut, totalWeights, masks, as_tex(L.kparam4), flows, white, black, L.W, L.H,
                                          c.scale, strideOut, mask0->pitch, freshNow, stream));
@@ -644,11 +687,36 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
         TRY(mfsr_fill_f32((float*)mask->ptr, (size_t)mask->pitch / 4 * mask->h, 1.0f, stream));
     } else {
         TRY(prepare_frame(b, raw, L.movHalf, L.movPyr, stream));
-        TRY(track_tiles(b, stream));
+        // I: global pre-alignment (base shift + rotation of this frame against the reference), kept in device memory
+        mfsr_prealign hostBase;
+        const mfsr_prealign* hb = nullptr;
+        if (c.preAlign) {
+            TRY(mfsr_preAlignPyramid((const float*)L.movPyr[0].ptr, L.tw, L.th, L.movPyr[0].pitch, L.preMovPyr, stream));
+            TRY(mfsr_preAlign(L.preRefPyr, L.preMovPyr, L.tw, L.th, c.preAlignMaxAngle, L.preWork, L.preResult, stream));
+            if (!c.fused) {
+                // the reference-shaped entry points take baseShift / baseRotation by value: one host round trip
+                MFSR_HIP_TRY(hipMemcpyAsync(&hostBase, L.preResult, sizeof(hostBase), hipMemcpyDeviceToHost, mfsr_s(stream)));
+                MFSR_HIP_TRY(hipStreamSynchronize(mfsr_s(stream)));
+                hb = &hostBase;
+            }
+        }
+        TRY(track_tiles(b, hb, stream));
         const int last = c.levels - 1;
         const mfsr_float2 zero2 = {0.0f, 0.0f};
-        TRY(mfsr_CreateFlowFieldFromTiles((mfsr_float2*)flow->ptr, as_tex(L.shifts[last]), c.tileSize[last], L.tcx[last],
-                                          L.tcy[last], L.tw, L.th, flow->pitch, zero2, 0.0f, stream));
+        if (c.preAlign && c.fused) {
+            TRY(mfsr_CreateFlowFieldFromTilesBase((mfsr_float2*)flow->ptr, as_tex(L.shifts[last]), L.tw, L.th, flow->pitch,
+                                                  L.preResult, stream));
+        } else {
+            mfsr_float2 base = zero2;
+            float rot = 0.0f;
+            if (hb) {
+                base.x = hb->shiftX;
+                base.y = hb->shiftY;
+                rot = hb->rotation;
+            }
+            TRY(mfsr_CreateFlowFieldFromTiles((mfsr_float2*)flow->ptr, as_tex(L.shifts[last]), c.tileSize[last], L.tcx[last],
+                                              L.tcy[last], L.tw, L.th, flow->pitch, base, rot, stream));
+        }
         for (int it = 0; it < c.lkIterations; it++) {
             if (c.fused) {
                 TRY(mfsr_lucasKanadeIterationFused((const mfsr_float2*)flow->ptr, (mfsr_float2*)other->ptr, flow->pitch,
@@ -772,6 +840,15 @@ extern "C" int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2
     if (mask) *mask = as_tex(*b->maskCur);
     if (kernelParam) *kernelParam = as_tex(b->L.kparam4);
     if (tracking) *tracking = as_tex(b->L.refPyr[0]);
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_burst_prealign_result(mfsr_burst* b, mfsr_prealign* hostOut, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && hostOut);
+    MFSR_REQUIRE(b->cfg.preAlign && b->L.preResult);
+    MFSR_HIP_TRY(hipMemcpyAsync(hostOut, b->L.preResult, sizeof(*hostOut), hipMemcpyDeviceToHost, mfsr_s(stream)));
+    MFSR_HIP_TRY(hipStreamSynchronize(mfsr_s(stream)));
     return MFSR_OK;
 }
 

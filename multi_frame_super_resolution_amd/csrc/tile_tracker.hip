@@ -165,12 +165,10 @@ extern "C" int mfsr_normalizedCC(const float* ccImage, const float* squaredTempl
 // ---- B1/B2: convertToTilesOverlapBorder / PreShift (kernel.cu:265-378) ---------
 // source pixel of tile-local (pxX,pxY): base shift + rotation about the image
 // centre, roundf, float clamp (:299-313 / :358-372)
-__device__ __forceinline__ float tile_fetch(const float* __restrict__ inImg, int imgWidth, int imgHeight, int imgPitch,
-                                            int tileSize, int tileIdxX, int tileIdxY, int pxX, int pxY, float2 shift,
-                                            float2 baseShift, float baseRotation)
+__device__ __forceinline__ float tile_fetch_cs(const float* __restrict__ inImg, int imgWidth, int imgHeight, int imgPitch,
+                                               int tileSize, int tileIdxX, int tileIdxY, int pxX, int pxY, float2 shift,
+                                               float2 baseShift, float cf, float sf)
 {
-    const float sf = sinf(baseRotation);
-    const float cf = cosf(baseRotation);
     shift.x += cf * -baseShift.x - sf * -baseShift.y;
     shift.y += sf * -baseShift.x + cf * -baseShift.y;
     const float patchCenterX = (float)(tileIdxX * tileSize + tileSize / 2 - imgWidth / 2);
@@ -182,6 +180,14 @@ __device__ __forceinline__ float tile_fetch(const float* __restrict__ inImg, int
     pxInImgX = f2i(fminf(fmaxf((float)pxInImgX, 0.0f), (float)(imgWidth - 1)));
     pxInImgY = f2i(fminf(fmaxf((float)pxInImgY, 0.0f), (float)(imgHeight - 1)));
     return row_ptr(inImg, imgPitch, pxInImgY)[pxInImgX];
+}
+
+__device__ __forceinline__ float tile_fetch(const float* __restrict__ inImg, int imgWidth, int imgHeight, int imgPitch,
+                                            int tileSize, int tileIdxX, int tileIdxY, int pxX, int pxY, float2 shift,
+                                            float2 baseShift, float baseRotation)
+{
+    return tile_fetch_cs(inImg, imgWidth, imgHeight, imgPitch, tileSize, tileIdxX, tileIdxY, pxX, pxY, shift, baseShift,
+                         cosf(baseRotation), sinf(baseRotation));
 }
 
 template <bool PRESHIFT>
@@ -696,7 +702,8 @@ __global__ void __launch_bounds__(TRK_THREADS)
     k_trackTilesFused(const float* __restrict__ refImg, const float* __restrict__ movedImg,
                       const float2* __restrict__ preShift, int preShiftPitch, float2* __restrict__ coordinates,
                       int coordinatesPitch, int imgWidth, int imgHeight, int imgPitch, int maxShift, int tileSize,
-                      int tileCountX, int tileCountY, float threshold, const float* __restrict__ refSq, int tilesPerWg)
+                      int tileCountX, int tileCountY, float threshold, const float* __restrict__ refSq, int tilesPerWg,
+                      const mfsr_prealign* __restrict__ base, float baseInvScale)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int T = tileSize, S = maxShift, L = T + 2 * S, R = 2 * S + 1;
@@ -708,6 +715,15 @@ __global__ void __launch_bounds__(TRK_THREADS)
     const int tileCount = tileCountX * tileCountY;
     const int tile0 = blockIdx.x * tilesPerWg;
     const float2 zero2 = make_float2(0.0f, 0.0f);
+    // global pre-alignment of the moved frame (B2's baseShift / baseRotation, kernel.cu:358-368), read from device
+    // memory: base shift in pixels of THIS pyramid level, cos/sin of the base rotation from the host-built table
+    float2 baseShift = zero2;
+    float baseCos = 1.0f, baseSin = 0.0f;
+    if (base) {
+        baseShift = make_float2(base->shiftX * baseInvScale, base->shiftY * baseInvScale);
+        baseCos = base->cosRotation;
+        baseSin = base->sinRotation;
+    }
     auto slot_ref = [&](int s) { return s_mem + s * slotFloats; };
     auto slot_mov = [&](int s) { return s_mem + s * slotFloats + nRef; };
     auto slot_row = [&](int s) { return s_mem + s * slotFloats + nRef + nMov; };
@@ -742,8 +758,8 @@ __global__ void __launch_bounds__(TRK_THREADS)
                 const int k = min(k0 + u * TRK_THREADS, nMov - 1);
                 const int y = k / Lp, x = k - y * Lp;
                 // the pad columns / tail read a valid pixel and are zeroed below
-                const float f = tile_fetch(movedImg, imgWidth, imgHeight, imgPitch, T, tileIdxX, tileIdxY, min(x, L - 1),
-                                           min(y, L - 1), pre, zero2, 0.0f);
+                const float f = tile_fetch_cs(movedImg, imgWidth, imgHeight, imgPitch, T, tileIdxX, tileIdxY, min(x, L - 1),
+                                              min(y, L - 1), pre, baseShift, baseCos, baseSin);
                 v[u] = (y < L && x < L) ? f : 0.0f;
             }
 #pragma unroll
@@ -875,10 +891,11 @@ extern "C" int mfsr_tileSquaredSums(const float* refImg, float* outValues, int i
     return mfsr_launch_status("tileSquaredSums");
 }
 
-extern "C" int mfsr_trackTilesFused(const float* refImg, const float* movedImg, const mfsr_float2* preShift,
-                                    int preShiftPitch, mfsr_float2* coordinates, int coordinatesPitch, int imgWidth,
-                                    int imgHeight, int imgPitch, int maxShift, int tileSize, int tileCountX,
-                                    int tileCountY, float threshold, const float* refSquaredSums, mfsr_stream_t stream)
+extern "C" int mfsr_trackTilesFusedBase(const float* refImg, const float* movedImg, const mfsr_float2* preShift,
+                                        int preShiftPitch, mfsr_float2* coordinates, int coordinatesPitch, int imgWidth,
+                                        int imgHeight, int imgPitch, int maxShift, int tileSize, int tileCountX,
+                                        int tileCountY, float threshold, const float* refSquaredSums,
+                                        const mfsr_prealign* base, float baseInvScale, mfsr_stream_t stream)
 {
     MFSR_REQUIRE(refImg && movedImg && coordinates && imgWidth > 0 && imgHeight > 0);
     MFSR_REQUIRE((long long)imgPitch >= 4LL * imgWidth && (imgPitch & 3) == 0);
@@ -904,7 +921,7 @@ extern "C" int mfsr_trackTilesFused(const float* refImg, const float* movedImg, 
     hipLaunchKernelGGL(k_trackTilesFused<N>, dim3(mfsr_cdiv(tiles, tilesPerWg)), dim3(TRK_THREADS), lds, mfsr_s(stream),  \
                        refImg, movedImg, (const float2*)preShift, preShiftPitch, (float2*)coordinates, coordinatesPitch, \
                        imgWidth, imgHeight, imgPitch, maxShift, tileSize, tileCountX, tileCountY, threshold,           \
-                       refSquaredSums, tilesPerWg)
+                       refSquaredSums, tilesPerWg, base, baseInvScale)
     if (nsx == 1)
         TRK_LAUNCH(1);
     else if (nsx == 2)
@@ -913,4 +930,14 @@ extern "C" int mfsr_trackTilesFused(const float* refImg, const float* movedImg, 
         TRK_LAUNCH(3);
 #undef TRK_LAUNCH
     return mfsr_launch_status("trackTilesFused");
+}
+
+extern "C" int mfsr_trackTilesFused(const float* refImg, const float* movedImg, const mfsr_float2* preShift,
+                                    int preShiftPitch, mfsr_float2* coordinates, int coordinatesPitch, int imgWidth,
+                                    int imgHeight, int imgPitch, int maxShift, int tileSize, int tileCountX,
+                                    int tileCountY, float threshold, const float* refSquaredSums, mfsr_stream_t stream)
+{
+    return mfsr_trackTilesFusedBase(refImg, movedImg, preShift, preShiftPitch, coordinates, coordinatesPitch, imgWidth, imgHeight,
+                                    imgPitch, maxShift, tileSize, tileCountX, tileCountY, threshold, refSquaredSums, nullptr, 1.0f,
+                                    stream);
 }

@@ -1,0 +1,130 @@
+"""Classification of HIP-vs-oracle differences of the burst pipeline (test helper).
+
+The per-pixel flow is the only non-bit-exact intermediate of the path (the Lucas-Kanade solve uses
+atan2/cos/sin/sqrt: ocml and glibc agree to 1-2 ulp, CUDA's own differ from both), and it reaches the fused image
+only through three discontinuities (oracle/diagnostics.c):
+
+  (1) round(s * flow)   per HR pixel     accumulateImagesSuperRes, DeBayerKernels.cu:403-406
+  (2) round(0.5 * flow) per half-res px  ComputeRobustnessMask, RobustnessModell.cu:76-77
+  (3) M > thresholdM    per half-res px  ComputeRobustnessMask, RobustnessModell.cu:147-148
+plus, on the accumulated weights,
+  (4) weight < threshold per channel     ApplyWeighting, kernel.cu:444-462
+
+``FlipSet`` collects, frame by frame, the HR pixels whose value can be affected by a flip of (1)-(4) between the two
+implementations (the "flip set"); everywhere else the two outputs must agree to +-1 LSB with NO exception.
+A pixel is also put in the set when either side is within ``tie_eps`` of a rounding tie / of the threshold: the HIP
+kernels evaluate the same bilinear blend with the weights in another order (1 ulp), so a value that close to a tie
+may flip inside the kernel without showing in the recomputed roundings.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _pitch(a):
+    return int(a.strides[0])
+
+
+def _dilate(m: np.ndarray, r: int) -> np.ndarray:
+    """Binary dilation by a (2r+1)^2 box (numpy only)."""
+    out = m.copy()
+    H, W = m.shape
+    for dy in range(-r, r + 1):
+        ys, yd = (slice(max(dy, 0), H + min(dy, 0)), slice(max(-dy, 0), H + min(-dy, 0)))
+        for dx in range(-r, r + 1):
+            xs, xd = (slice(max(dx, 0), W + min(dx, 0)), slice(max(-dx, 0), W + min(-dx, 0)))
+            out[yd, xd] |= m[ys, xs]
+    return out
+
+
+def _near_tie(v: np.ndarray, eps: float) -> np.ndarray:
+    """|v - (n + 0.5)| < eps*max(1,|v|) for some integer n, any component."""
+    fr = np.abs(v - np.floor(v) - 0.5)
+    return (fr < eps * np.maximum(1.0, np.abs(v))).any(-1)
+
+
+class FlipSet:
+    def __init__(self, cfg, tie_eps: float = 4e-6):
+        from oracle.bindings import oracle
+        self.o = oracle()
+        self.c = cfg
+        self.s = cfg.scale
+        self.W, self.H = cfg.width, cfg.height
+        self.hw, self.hh = self.W // 2, self.H // 2
+        self.hrW, self.hrH = self.W * self.s, self.H * self.s
+        self.tie_eps = tie_eps
+        self.flips = np.zeros((self.hrH, self.hrW), bool)
+        self.n = dict(fuse_round=0, robust_round=0, robust_M=0, weight_threshold=0)
+        self.frames = 0
+        self.max_flow_diff = 0.0
+
+    def _fuse_shifts(self, flow):
+        val = np.zeros((self.hrH, self.hrW, 2), np.float32)
+        sh = np.zeros((self.hrH, self.hrW, 2), np.int32)
+        self.o.dbgFuseShifts(flow, _pitch(flow), flow.shape[1], flow.shape[0], self.W, self.H, self.s, val, sh)
+        return val, sh
+
+    def _robust_shifts(self, flow):
+        val = np.zeros((self.hh, self.hw, 2), np.float32)
+        sh = np.zeros((self.hh, self.hw, 2), np.int32)
+        self.o.dbgRobustnessShifts(flow, _pitch(flow), flow.shape[1], flow.shape[0], self.hw, self.hh, val, sh)
+        return val, sh
+
+    def add_frame(self, flow_h, flow_o, mask_h, mask_o):
+        """flow_*: [th, tw, 2] float32 (raw-pixel units, what the fuse and robustness kernels read);
+        mask_*: [hh, hw, 4] float32 (.w = M)."""
+        flow_h = np.ascontiguousarray(flow_h, np.float32)
+        flow_o = np.ascontiguousarray(flow_o, np.float32)
+        self.frames += 1
+        self.max_flow_diff = max(self.max_flow_diff, float(np.abs(flow_h - flow_o).max()))
+        # (1)
+        vh, sh = self._fuse_shifts(flow_h)
+        vo, so = self._fuse_shifts(flow_o)
+        f1 = (sh != so).any(-1) | ((vh != vo).any(-1) & (_near_tie(vh, self.tie_eps) | _near_tie(vo, self.tie_eps)))
+        self.n["fuse_round"] += int(f1.sum())
+        self.flips |= f1
+        # (2) + (3), half resolution
+        rvh, rsh = self._robust_shifts(flow_h)
+        rvo, rso = self._robust_shifts(flow_o)
+        f2 = (rsh != rso).any(-1) | ((rvh != rvo).any(-1) & (_near_tie(rvh, self.tie_eps) | _near_tie(rvo, self.tie_eps)))
+        thr = float(self.c.thresholdM)
+        Mh, Mo = mask_h[..., 3], mask_o[..., 3]
+        f3 = ((Mh > thr) != (Mo > thr)) | ((Mh != Mo) & ((np.abs(Mh - thr) < 1e-5 * thr) | (np.abs(Mo - thr) < 1e-5 * thr)))
+        self.n["robust_round"] += int(f2.sum())
+        self.n["robust_M"] += int(f3.sum())
+        fm = f2 | f3
+        if fm.any():
+            # certainty site of HR pixel X, tap px: floor((X+px)/s)/2, px in [-2,2]  ->  half-res pixel x is read by
+            # X in [2s*x - 2, 2s*x + 2s + 1]
+            up = np.repeat(np.repeat(fm, 2 * self.s, 0), 2 * self.s, 1)[:self.hrH, :self.hrW]
+            self.flips[:up.shape[0], :up.shape[1]] |= _dilate(up, 2)
+
+    def add_weights(self, tw_h, tw_o):
+        """(4): the accumulated weights on either side of ApplyWeighting's threshold."""
+        thr = float(self.c.weightThreshold)
+        f4 = ((tw_h < thr) != (tw_o < thr)).any(-1)
+        self.n["weight_threshold"] += int(f4.sum())
+        self.flips |= f4
+
+    def report(self, h_out, o_out, h16, o16):
+        """Error statistics inside / outside the flip set (8 bit: the CLI's output depth; 16 bit as the finer diagnostic)."""
+        d8 = np.abs(np.round(np.clip(h_out, 0, 1) * 255.0) - np.round(np.clip(o_out, 0, 1) * 255.0)).max(-1)
+        d16 = np.abs(h16.astype(np.int64) - o16.astype(np.int64)).max(-1)
+        E = self.flips
+        inside, outside = E, ~E
+        tot = float(E.size)
+        r = {
+            "flip_fraction": float(E.sum()) / tot,
+            "flips_by_cause_per_frame": {k: v / max(self.frames, 1) / tot for k, v in self.n.items()},
+            "max_flow_diff_px": self.max_flow_diff,
+            "max8_inside": int(d8[inside].max()) if inside.any() else 0,
+            "max8_outside": int(d8[outside].max()) if outside.any() else 0,
+            "n_gt1_8bit_inside": int((d8[inside] > 1).sum()),
+            "n_gt1_8bit_outside": int((d8[outside] > 1).sum()),
+            "max16_inside": int(d16[inside].max()) if inside.any() else 0,
+            "max16_outside": int(d16[outside].max()) if outside.any() else 0,
+            "frac_gt1_16bit_outside": float((d16[outside] > 1).sum()) / tot,
+            "frac_gt1_8bit": float((d8 > 1).sum()) / tot,
+            "frac_gt1_16bit": float((d16 > 1).sum()) / tot,
+        }
+        return r

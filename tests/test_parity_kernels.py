@@ -802,9 +802,12 @@ def test_lucasKanadeOptim(orc, hip, hw):
     assert_bitexact(o[:hw], sh0[:hw])   # border ring untouched
 
 
-def test_lucasKanadeIterationFused_equals_chain(orc, hip):
-    """Fused D2+D3+D4 == oracle chain Warping -> ComputeDerivatives(source=warped, target=ref) -> lucasKanadeOptim."""
-    H, W, hw = 70, 100, 3
+@pytest.mark.parametrize("hw", [3, 0, 1, 2, 6, 7, 8])
+def test_lucasKanadeIterationFused_equals_chain(orc, hip, hw):
+    """Fused D2+D3+D4 == oracle chain Warping -> ComputeDerivatives(source=warped, target=ref) -> lucasKanadeOptim,
+    for every dispatch arm of the host (half windows 1..7 have <h,48> and <h,32> kernels, all others the generic
+    <0,32> one; W=100 is wide enough for the 48-wide tiles)."""
+    H, W = 70, 100
     base = _smooth_image(56, H + 8, W + 8)
     ref = np.ascontiguousarray(base[4:4 + H, 4:4 + W])
     mov = np.ascontiguousarray(base[3:3 + H, 6:6 + W])
@@ -826,12 +829,22 @@ def test_lucasKanadeIterationFused_equals_chain(orc, hip):
     hip.call("scaleFlow", scaled, pitch_of(scaled), W, H, 2.0)
     assert_bitexact(scaled, out2, "lucasKanadeIterationFused(outScale)")
     # separable window sums + M^-1 * sum(grad*It) instead of sum(M^-1 grad * It): rounding only
-    np.testing.assert_allclose(out, flow, atol=1e-4)
+    if hw >= 2:
+        np.testing.assert_allclose(out, flow, atol=1e-4)
+    elif hw == 1:
+        # 3x3 windows are often nearly singular: the pseudo-inverse amplifies the rounding of the sums
+        assert np.mean(np.abs(out - flow) > 1e-3) < 2e-2
+    else:
+        # 1x1 window: the normal matrix has rank 1, sigma2 = sqrt((S1 - S2)/2) is 0, NaN or 1e-4 by rounding alone
+        # (opticalFlow.cu:251-259), in the reference as much as here: only the launch geometry is checked
+        assert out.shape == flow.shape and not np.any(out == 99)
+    assert_bitexact(out[:hw], flow0[:hw], "ring rows")   # the h-px ring keeps the input flow
     assert np.abs(flow - flow0).max() > 0.05   # the iteration did move the flow
-    # true shift is (-2, +1): one iteration gets closer
-    err0 = np.abs(flow0[10:-10, 10:-10] - [-2, 1]).mean()
-    err1 = np.abs(out[10:-10, 10:-10] - [-2, 1]).mean()
-    assert err1 < err0
+    if hw >= 2:
+        # true shift is (-2, +1): one iteration gets closer
+        err0 = np.abs(flow0[10:-10, 10:-10] - [-2, 1]).mean()
+        err1 = np.abs(out[10:-10, 10:-10] - [-2, 1]).mean()
+        assert err1 < err0
 
 
 def test_structure_tensor_and_kernel_param(orc, hip):

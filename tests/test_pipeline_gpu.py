@@ -1,19 +1,25 @@
 """GPU parity of the whole burst pipeline (C-ABI mfsr_burst_*) against the CPU
 oracle pipeline on the same synthetic bursts, plus size-independent properties
-at BASELINE.json's full frame size.
+at BASELINE.json's full frame sizes.
 
 Tolerance (north_star): outputs within +-1 LSB per channel.  Kernel-level parity
-is bit-exact or ~1e-6 (tests/test_parity_kernels.py); at pipeline level the
-v_exp_f32 weights, ocml-vs-glibc transcendentals in the Lucas-Kanade solve and
-re-ordered window sums perturb the flow by ~1e-5 px, which can flip a
-roundf(s*flow) at a handful of pixels.  So the end-to-end criteria are:
-+-1 LSB at 8 bit for >= 99.9 % of the samples, +-1 LSB at 16 bit for >= 99 %,
-PSNR vs the oracle >= 70 dB, and the fraction of out-of-budget pixels is printed.
+is bit-exact or ~1e-6 (tests/test_parity_kernels.py).  At pipeline level the only
+non-bit-exact intermediate is the per-pixel flow (the Lucas-Kanade solve evaluates
+atan2/cos/sin/sqrt: 1-2 ulp between ocml and glibc, ~1e-5 px on the flow), and the
+flow reaches the image only through roundings and thresholds.  tests/flipset.py
+recomputes those decisions for both implementations from their own per-frame flows
+and masks; the contract asserted here (tests/burst_compare.py::assert_parity) is
+
+  * outside the flip set: NO 8-bit sample differs by more than 1 LSB;
+  * the flip set is a small fraction of the image and is printed with its causes;
+  * PSNR vs the oracle >= 70 dB, 8-bit samples off by >1 LSB <= 1e-3 overall.
 """
 import ctypes
 
 import numpy as np
 import pytest
+
+from tests.burst_compare import assert_parity, classify, psnr as _psnr, run_hip, run_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -26,42 +32,24 @@ def _cfg(W, H, N, scale, mono, fused):
 
 
 def _run_hip(cfg, frames):
-    import torch
-    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, view_as_tensor
-    dev = torch.device("cuda:0")
-    pipe = BurstPipeline(cfg, dev)
-    dframes = [f.to(dev) for f in frames]
-    out, out16 = pipe.process(dframes)
-    torch.cuda.synchronize()
-    flow_t, mask_t, kp_t, trk_t = pipe.debug_views()
-    res = dict(out=out.cpu().numpy(), out16=out16.cpu().numpy().view(np.uint16), img_out=pipe.img_out.cpu().numpy(),
-               tw=pipe.total_weights.cpu().numpy(), flow=view_as_tensor(flow_t, 2, dev).cpu().numpy(),
-               mask=view_as_tensor(mask_t, 4, dev).cpu().numpy(), kparam=view_as_tensor(kp_t, 4, dev).cpu().numpy(),
-               tracking=view_as_tensor(trk_t, 1, dev).cpu().numpy()[..., 0])
-    pipe.close()
-    return res
+    return run_hip(cfg, frames)
 
 
 def _run_oracle(cfg, frames):
-    from oracle.pipeline import OraclePipeline
-    op = OraclePipeline(cfg)
-    nf = [f.numpy().view(np.uint16) for f in frames]
-    out, q = op.process(nf)
-    return dict(out=out, out16=q, flow=op.flow, mask=op.mask, kparam=op.kparam4, tracking=op.ref_pyr[0])
+    return run_oracle(cfg, frames)
 
 
-def _psnr(a, b, peak=1.0):
-    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
-    return 200.0 if mse == 0 else 10 * np.log10(peak * peak / mse)
-
-
-def _check_outputs(h, o, what):
+def _check_outputs(h, o, what, cfg=None):
+    """HIP vs oracle with the flip-set classification (cfg given), or HIP vs HIP variants (no cfg: plain statistics)."""
+    if cfg is not None:
+        assert_parity(classify(cfg, h, o), what)
+        return
     d16 = np.abs(h["out16"].astype(np.int64) - o["out16"].astype(np.int64))
     d8 = np.abs(np.round(h["out"] * 255.0) - np.round(o["out"] * 255.0))
     frac16 = float(np.mean(d16 > 1))
     frac8 = float(np.mean(d8 > 1))
     psnr = _psnr(h["out"], o["out"])
-    print(f"[{what}] PSNR vs oracle {psnr:.1f} dB; >1 LSB: 8-bit {frac8:.2e}, 16-bit {frac16:.2e}; max16 {d16.max()}")
+    print(f"[{what}] PSNR {psnr:.1f} dB; >1 LSB: 8-bit {frac8:.2e}, 16-bit {frac16:.2e}; max16 {d16.max()}")
     assert psnr >= 70.0
     assert frac8 <= 1e-3
     assert frac16 <= 1e-2
@@ -86,7 +74,7 @@ def test_burst_matches_oracle(mono, fused, scale):
     print(f"flow: max |d| {dflow.max():.2e} px, mean {dflow.mean():.2e}")
     assert np.mean(dflow > 1e-3) < 1e-3
     assert np.mean(np.abs(h["mask"][..., :3] - o["mask"][..., :3]) > 1e-3) < 1e-2
-    _check_outputs(h, o, f"mono={mono} fused={fused} s={scale}")
+    _check_outputs(h, o, f"mono={mono} fused={fused} s={scale}", cfg)
     # the alignment actually locks on: flow ~ -(shift of the last frame) in raw px (centre region)
     fs = 1 if mono else 2
     true = -shifts[N - 1].numpy()
@@ -110,7 +98,7 @@ def test_burst_matches_oracle_ragged_sizes(W, H, N, scale, cfa):
     np.testing.assert_allclose(h["tracking"], o["tracking"], atol=1e-6)
     dflow = np.abs(h["flow"] - o["flow"])
     assert np.mean(dflow > 1e-3) < 1e-3
-    _check_outputs(h, o, f"{W}x{H} N={N} s={scale} {cfa}")
+    _check_outputs(h, o, f"{W}x{H} N={N} s={scale} {cfa}", cfg)
 
 
 def test_super_resolution_beats_single_frame():
@@ -331,3 +319,96 @@ def test_sliding_window_stream_equals_bursts(scale):
     assert not torch.equal(stream[1], stream[2])
     pipe.close()
     ref.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs at their own sizes
+# ---------------------------------------------------------------------------------------------------------------------
+def _flow_locks(h, shifts, k, fs):
+    """median flow of frame k in the centre region ~ -(true shift) in raw px"""
+    f = h["flows"][k]
+    c = f[f.shape[0] // 4: -f.shape[0] // 4, f.shape[1] // 4: -f.shape[1] // 4]
+    np.testing.assert_allclose(np.median(c.reshape(-1, 2), 0), -shifts[k].cpu().numpy(), atol=0.15)
+
+
+def test_config1_1080p_gray_x2_vs_oracle():
+    """BASELINE configs[1] frame size (1920x1080 gray, x2) on a 2-frame sample against the oracle."""
+    from multi_frame_super_resolution_amd.synth import make_burst
+    W, H, N = 1920, 1080, 2
+    frames, shifts, _ = make_burst(W, H, N, scale=2, mono=True, seed=1234 + 1)
+    cfg = _cfg(W, H, N, 2, True, 1)
+    h = run_hip(cfg, frames)
+    o = run_oracle(cfg, frames)
+    np.testing.assert_allclose(h["tracking"], o["tracking"], atol=1e-6)
+    _flow_locks(h, shifts, 1, 1)
+    assert_parity(classify(cfg, h, o), "configs[1] 1080p gray x2, 2-frame sample")
+
+
+def test_config2_4k_rggb_x2_sample_vs_oracle():
+    """BASELINE configs[2] frame size (3840x2160 RGGB, x2), 4 moved-and-noisy frames, against the oracle: the
+    asserted version of bench.py's cpu_baseline.parity_on_sample."""
+    from multi_frame_super_resolution_amd.synth import make_burst
+    W, H, N = 3840, 2160, 4
+    frames, shifts, _ = make_burst(W, H, N, scale=2, mono=False, seed=1234 + 2)
+    cfg = _cfg(W, H, N, 2, False, 1)
+    h = run_hip(cfg, frames)
+    o = run_oracle(cfg, frames)
+    for k in range(1, N):
+        _flow_locks(h, shifts, k, 2)
+    assert_parity(classify(cfg, h, o), "configs[2] 4K RGGB x2, 4-frame sample")
+
+
+def test_config3_x4_crop_vs_oracle():
+    """BASELINE configs[3] scale (x4) at 1024x768 (12 Mpix HR grid, every tile path of k_accumulate4xTile, partial
+    tiles on both axes) against the oracle."""
+    from multi_frame_super_resolution_amd.synth import make_burst
+    W, H, N = 1024, 768, 3
+    frames, shifts, _ = make_burst(W, H, N, scale=4, mono=False, seed=1234 + 3, max_shift=4.0)
+    cfg = _cfg(W, H, N, 4, False, 1)
+    h = run_hip(cfg, frames)
+    o = run_oracle(cfg, frames)
+    for k in range(1, N):
+        _flow_locks(h, shifts, k, 2)
+    assert_parity(classify(cfg, h, o), "configs[3] x4 at 1024x768")
+
+
+def test_config3_full_size_properties_4k_x4():
+    """BASELINE configs[3] at full size (3840x2160 -> 15360x8640, 2 x 1.59 GB accumulators): properties that need no
+    oracle.  (a) determinism bit for bit; (b) frame pairing == frame by frame up to the re-association of two sums;
+    (c) the fused image of reference + moved frames stays within the sample range and the HR border ring is the
+    fallback; (d) a moved frame's flow locks onto its true shift at this size."""
+    import torch
+    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, view_as_tensor
+    from multi_frame_super_resolution_amd.synth import make_burst
+    dev = torch.device("cuda:0")
+    W, H, N = 3840, 2160, 3
+    frames, shifts, _ = make_burst(W, H, N, scale=4, mono=False, seed=1234 + 3, device=dev)
+    outs = {}
+    for pair in (1, 0):
+        cfg = _cfg(W, H, N, 4, False, 1)
+        cfg.pairFrames = pair
+        pipe = BurstPipeline(cfg, dev)
+        assert pipe.hr_w == 15360 and pipe.hr_h == 8640
+        _, o16 = pipe.process(frames)
+        first = o16.clone()
+        if pair:
+            flow_t = pipe.debug_views()[0]
+            fl = view_as_tensor(flow_t, 2, dev)
+            c = fl[fl.shape[0] // 4: -fl.shape[0] // 4, fl.shape[1] // 4: -fl.shape[1] // 4].reshape(-1, 2)
+            med = c.median(0).values.cpu().numpy()
+            np.testing.assert_allclose(med, -shifts[N - 1].cpu().numpy(), atol=0.15)
+            _, again = pipe.process(frames)
+            assert torch.equal(again, first)                       # (a)
+            tw = pipe.total_weights
+            assert float(tw[0].abs().max()) == 0.0 and float(tw[:, 0].abs().max()) == 0.0   # (c) ring untouched
+            assert float(tw[8:-8, 8:-8].sum(-1).min()) > 0.0     # every interior HR pixel collected weight
+            out = pipe.out_img
+            assert torch.isfinite(out).all() and 0.05 < float(out.mean()) < 0.95
+        outs[pair] = first.view(torch.uint8).view(-1)   # u16 bit patterns as bytes
+        pipe.close()
+        del pipe
+        torch.cuda.empty_cache()
+    a = outs[1].view(torch.int16).to(torch.int32) & 0xFFFF
+    b = outs[0].view(torch.int16).to(torch.int32) & 0xFFFF
+    d = (a - b).abs()
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3   # (b)
