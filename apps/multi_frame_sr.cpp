@@ -249,17 +249,23 @@ int main(int argc, char** argv)
         return -1;
     }
 
-    // load the burst (reference indexes i%num_images+1; the bundled city frames are 0..4 -> try both)
+    // load the burst.  The reference indexes its frames i%num_images+1 (multi_frame_sr.cpp:171) while the frames bundled
+    // with it are numbered from 0 (test_opencv/img_00000[0-4].png): use 1-based names when the last 1-based file exists,
+    // 0-based names otherwise.
     std::vector<Image8> imgs(num_images);
     char buf[BUFSIZ];
+    int firstIndex = 1;
+    {
+        snprintf(buf, sizeof(buf), filenameFormat.c_str(), num_images);
+        FILE* probe = fopen(buf, "rb");
+        if (probe)
+            fclose(probe);
+        else
+            firstIndex = 0;
+    }
     for (int i = 0; i < num_images; i++) {
-        snprintf(buf, sizeof(buf), filenameFormat.c_str(), i + 1);
-        bool ok = read_image(buf, imgs[i]);
-        if (!ok) {
-            snprintf(buf, sizeof(buf), filenameFormat.c_str(), i);
-            ok = read_image(buf, imgs[i]);
-        }
-        if (!ok) {
+        snprintf(buf, sizeof(buf), filenameFormat.c_str(), i + firstIndex);
+        if (!read_image(buf, imgs[i])) {
             fprintf(stderr, "cannot read frame %d of '%s' (%s): PNG or binary PNM expected\n", i, inputName.c_str(), buf);
             return 1;
         }
@@ -289,6 +295,8 @@ int main(int argc, char** argv)
     mfsr_config cfg;
     MFSR_OK_OR_DIE(mfsr_config_default(&cfg, W, H, num_images, scale, 0));
     cfg.lkIterations = iterations;
+    cfg.preAlign = 1;  // hand-held bursts: base shift + rotation per frame before the tile tracker (the bundled city frames
+                       // are rotated by up to 15 degrees, test_opencv/main.cpp:1896)
     for (int c = 0; c < 3; c++) {
         cfg.black[c] = 0.0f;
         cfg.white[c] = 4080.0f;

@@ -48,16 +48,46 @@ WORKLOADS = {
     "8k8_rggb_x2": (7680, 4320, 8, 2, False),        # BASELINE configs[4]: 64-frame 8K burst = 8 frames per GPU at N = 8
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_CLOCK_GHZ = 2.4    # MI355X peak engine clock
 
 
-def fuse_bytes_per_launch(W, H, s, mono):
-    """ALGORITHMIC bytes of one accumulate launch (one frame), reference structure
-    (accumulators read-modify-written in HBM): HR*48 B for imgOut/totalWeights
-    (2 x float3 read + write) + the per-frame inputs at their stored resolution:
-    raw u16 (LR*2) + flow float2 + kernel-param float4 + certainty float4."""
-    lr, hr = W * H, W * H * s * s
+def fuse_input_bytes_per_frame(W, H, s, mono):
+    """Per-frame inputs of the warp+fuse kernel at their stored resolution: raw u16 (LR*2) + flow float2 +
+    certainty float4 (half res); the kernel-parameter float4 field is per launch, not per frame."""
+    lr = W * H
     trk = lr if mono else lr // 4          # flow / kernel-param field resolution
-    return hr * 48 + lr * 2 + trk * (8 + 16) + (lr // 4) * 16
+    return lr * 2 + trk * 8 + (lr // 4) * 16
+
+
+def fuse_bytes_reference_structure(W, H, s, mono):
+    """SURVEY.md section 8(d)'s reference-structure figure for ONE frame: one launch per frame, both accumulator
+    plane-sets read-modify-written in HBM (HR*48 B) + every input.  What the reference's kernel moves per frame; the
+    frame-paired kernel of this build moves the accumulators once per TWO frames, so this is NOT what it moves."""
+    lr, hr = W * H, W * H * s * s
+    trk = lr if mono else lr // 4
+    return hr * 48 + fuse_input_bytes_per_frame(W, H, s, mono) + trk * 16
+
+
+def fuse_bytes_must_move(W, H, s, mono, frames_in_launch, first_of_burst):
+    """ALGORITHMIC bytes one warp+fuse launch has to move: the two accumulator plane-sets once (read + write, HR*48 B;
+    the first launch of a burst overwrites them: HR*24 B), the kernel-parameter field once, and the per-frame inputs of
+    the frames it fuses."""
+    lr, hr = W * H, W * H * s * s
+    trk = lr if mono else lr // 4
+    return hr * (24 if first_of_burst else 48) + trk * 16 + frames_in_launch * fuse_input_bytes_per_frame(W, H, s, mono)
+
+
+def burst_fuse_bytes(W, H, s, mono, frames, pair):
+    """(launches, must-move bytes) of the warp+fuse launches of one burst of `frames` frames on one rank."""
+    per = 2 if pair else 1
+    launches, total, left, first = 0, 0, frames, True
+    while left > 0:
+        n = min(per, left)
+        total += fuse_bytes_must_move(W, H, s, mono, n, first)
+        first = False
+        left -= n
+        launches += 1
+    return launches, total
 
 
 def cpu_baseline(W, H, s, mono, sample_frames, seed):
@@ -84,24 +114,24 @@ def cpu_baseline(W, H, s, mono, sample_frames, seed):
         "sample": f"{sample_frames} frames of {W}x{H} (1 reference + {sample_frames - 1} moved), x{s}, "
                   f"whole pipeline, OpenMP, {dt:.1f} s",
     }
-    # the same sample through the HIP path: the "PSNR vs ref" half of BASELINE.json's metric (the oracle is
-    # only the checker here)
+    # the same sample through the HIP path: the "PSNR vs ref" half of BASELINE.json's metric, with the flip-set
+    # classification of tests/flipset.py (the oracle is only the checker here)
     try:
-        import torch
-        from multi_frame_super_resolution_amd.pipeline import BurstPipeline
-        dev = torch.device("cuda", torch.cuda.current_device())
-        hp = BurstPipeline(cfg, dev)
-        h_out, h_q = hp.process([f.to(dev) for f in frames])
-        h_out = h_out.cpu().numpy()
-        h_q = h_q.cpu().numpy().view(np.uint16)
-        hp.close()
-        mse = float(np.mean((h_out.astype(np.float64) - o_out.astype(np.float64)) ** 2))
-        d8 = np.abs(np.round(h_out * 255.0) - np.round(o_out * 255.0))
-        d16 = np.abs(h_q.astype(np.int64) - o_q.astype(np.int64))
+        from tests.burst_compare import classify, run_hip, run_oracle
+        h = run_hip(cfg, frames, device=f"cuda:{__import__('torch').cuda.current_device()}")
+        o = run_oracle(cfg, nf)   # per-frame flows and masks for the classification (not timed)
+        rep = classify(cfg, h, o)
         res["parity_on_sample"] = {
-            "psnr_db_vs_oracle": round(200.0 if mse == 0 else 10 * np.log10(1.0 / mse), 2),
-            "frac_gt_1lsb_8bit": float((d8 > 1).mean()),
-            "frac_gt_1lsb_16bit": float((d16 > 1).mean()),
+            "psnr_db_vs_oracle": rep["psnr_db_vs_oracle"],
+            "flip_fraction": rep["flip_fraction"],
+            "n_gt_1lsb_8bit_outside_flip_set": rep["n_gt1_8bit_outside"],
+            "max_8bit_outside_flip_set": rep["max8_outside"],
+            "max_8bit_inside_flip_set": rep["max8_inside"],
+            "frac_gt_1lsb_8bit": rep["frac_gt1_8bit"],
+            "frac_gt_1lsb_16bit": rep["frac_gt1_16bit"],
+            "max_flow_diff_px": rep["max_flow_diff_px"],
+            "note": "flip set = HR pixels where a rounding / threshold decision fed by the (non-bit-exact) Lucas-Kanade flow "
+                    "differs between HIP and oracle (tests/flipset.py); outside it every 8-bit sample is within 1 LSB",
         }
     except Exception as e:  # the throughput line must not depend on the checker
         res["parity_on_sample"] = {"error": repr(e)}
@@ -117,6 +147,7 @@ def main():
     ap.add_argument("--strong", action="store_true", help="fixed 16-frame burst sharded over the GPUs")
     ap.add_argument("--exchange", default="auto", choices=["auto", "reduce", "reduce_scatter"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the H2D->D2H end-to-end leg (median of 20 bursts)")
     ap.add_argument("--cpu-sample-frames", type=int, default=4)
     ap.add_argument("--unfused", action="store_true", help="one launch per reference kernel (A/B against the fused path)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -170,8 +201,10 @@ def main():
     cfg.fused = 0 if args.unfused else 1
     if args.no_pair:
         cfg.pairFrames = 0
-    if args.async_fuse and not args.h2d:   # (the upload ring of --h2d reuses a raw buffer right after the next add_frame)
+    if args.async_fuse:
         cfg.asyncFuse = 1
+    if world == 1:
+        cfg.uploadRing = 4      # device slots for --h2d and the end-to-end leg (mfsr_burst_*_host); unused by the resident run
     pipe = BurstPipeline(cfg, dev)
 
     # synthetic burst: one scene (same seed on every rank), this rank's frames only
@@ -199,39 +232,15 @@ def main():
         used = [False for _ in pipes]
 
     h2d = args.h2d and world == 1
-    if h2d:
-        # double-buffered upload: frame k is copied into ring slot k % 4 on the copy stream while the
-        # compute stream works on earlier frames; a slot is reused once the add_frame after its
-        # frame's own has been issued (frame pairing keeps a raw buffer one call longer)
+    host = None
+    if world == 1:
         order = sorted(frames.keys())
-        host = {k: frames[k].cpu().pin_memory() for k in order}
-        ring = [torch.empty_like(frames[order[0]]) for _ in range(4)]
-        copy_s = torch.cuda.Stream(device=dev)
-        prev_end = [None]
+        host = [frames[k].cpu().pin_memory() for k in order]   # pinned host copies for --h2d / the end-to-end leg
 
     def step_h2d():
-        main = torch.cuda.current_stream()
-        ev_up = [torch.cuda.Event() for _ in order]
-        ev_done = [torch.cuda.Event() for _ in order]
-        pipe.begin_burst()
-        for i, k in enumerate(order):
-            with torch.cuda.stream(copy_s):
-                if i >= 4:
-                    copy_s.wait_event(ev_done[i - 3])
-                elif prev_end[0] is not None:
-                    copy_s.wait_event(prev_end[0])
-                ring[i % 4].copy_(host[k], non_blocking=True)
-                ev_up[i].record(copy_s)
-            main.wait_event(ev_up[i])
-            if i == 0:
-                assert k == cfg.reference
-                pipe.set_reference(ring[0])
-            pipe.add_frame(ring[i % 4], k == cfg.reference)
-            ev_done[i].record(main)
-        _, out = pipe.finish(want_float=False, want_u16=True)
-        prev_end[0] = torch.cuda.Event()
-        prev_end[0].record(main)
-        return out
+        # frames start in pinned HOST memory; the library uploads them on its copy stream into a 4-slot device ring while
+        # the compute stream works on earlier frames (mfsr_burst_*_host), and copies the u16 result back
+        return pipe.process_host(host)
 
     def step():
         if h2d:
@@ -290,21 +299,56 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # SURVEY.md section 8(d)'s end-to-end figure, beside the HBM-resident `value`: wall time from the first H2D enqueue
+    # to the final D2H complete, one burst at a time, median of 20 (after 5 warm-up bursts)
+    e2e = None
+    if world == 1 and rank == 0 and not args.no_e2e:
+        import statistics
+        ts = []
+        for i in range(5 + 20):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            pipe.process_host(host)
+            torch.cuda.synchronize()
+            if i >= 5:
+                ts.append(time.perf_counter() - t1)
+        med = statistics.median(ts)
+        e2e = {
+            "value": round(n_frames * W * H / med / 1e6, 2), "unit": "Mpix/s", "ms_median": round(med * 1e3, 3),
+            "ms_min": round(min(ts) * 1e3, 3), "bursts": len(ts),
+            "includes": f"H2D of {n_frames} raw frames ({n_frames * W * H * 2 / 1e6:.0f} MB, pinned host memory, library copy "
+                        f"stream + 4-slot device ring) and D2H of the u16 HR image ({s * s * W * H * 6 / 1e6:.0f} MB); "
+                        "one burst in flight",
+        }
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = n_frames * W * H * args.steps / dt / 1e6
-        # algorithmic bytes of one launch = per-frame figure x the frames that launch fuses (2 with
-        # frame pairing, the default; the last frame of an odd shard goes alone)
-        bytes_frame = fuse_bytes_per_launch(W, H, s, mono)
+        # bytes a launch MUST move (accumulators once per launch, not once per frame) vs the reference-structure figure
+        n_launch_burst, bytes_burst = burst_fuse_bytes(W, H, s, mono, len(mine), bool(cfg.pairFrames))
+        bytes_launch = bytes_burst / n_launch_burst
         frames_per_launch = fused_frames.value / max(launches.value, 1)
-        bytes_launch = bytes_frame * frames_per_launch
+        bytes_ref_launch = fuse_bytes_reference_structure(W, H, s, mono) * frames_per_launch
         k_ms = tot_ms.value / max(launches.value, 1)
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
+        achieved_ref = bytes_ref_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic, valu = None, None
         tpath = os.path.join(ROOT, "profiles", "fuse_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload)
+                ent = json.load(open(tpath)).get(args.workload)
+                if isinstance(ent, dict):
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    vi = ent.get("valu_wave_insts_per_launch")
+                    if vi:
+                        # VALU-issue ceiling: every wave-level VALU instruction occupies its SIMD for 4 cycles (wave64 on a
+                        # 16-lane SIMD); 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock
+                        floor_ms = vi * 4 / (1024 * VALU_CLOCK_GHZ * 1e9) * 1e3
+                        valu = {"wave_insts_per_launch": vi, "cycles_per_inst": 4, "simds": 1024, "clock_ghz": VALU_CLOCK_GHZ,
+                                "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / k_ms, 4) if k_ms > 0 else None,
+                                "source": ent.get("source")}
+                elif ent is not None:
+                    traffic = ent
             except Exception:
                 traffic = None
         line = {
@@ -319,7 +363,8 @@ def main():
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" + (", streamed from pinned host memory (4-deep device ring, copy stream)" if h2d else ""),
+            "data": "synthetic" + (", streamed from pinned host memory (library copy stream, 4-slot device ring)" if h2d else
+                                   ", frames resident in HBM"),
             "config": {
                 "workload": f"{n_frames}-frame {W}x{H} {'gray' if mono else 'RGGB u16'} burst -> x{s} "
                             f"({args.workload}; BASELINE configs[{ {'4k16_rggb_x2': 2, '1080p5_gray_x2': 1, '4k16_rggb_x4': 3, '8k8_rggb_x2': 4}[args.workload] }])",
@@ -332,20 +377,32 @@ def main():
                 **({"rehearsal": "gloo backend, ranks share GPUs, collectives staged through the host: not a measurement"}
                    if (world > 1 and backend == "gloo") else {}),
             },
+            "end_to_end": e2e,
             "roofline": {
-                "kernel": ("k_accumulate2xTile / k_accumulate2xStrip" if s == 2 else "k_accumulateSuperRes<GEOM_FULL,fast>")
-                          + " (warp+fuse, accumulateSuperResFull[2]; launch = tile kernel + border kernel per frame)",
-                "bound": "hbm",
+                "kernel": ("k_accumulate2xTile / k_accumulate2xStrip" if s == 2 else "k_accumulate4xTile")
+                          + " (warp+fuse, accumulateSuperResFullN; a launch = the tile kernel + the margin kernel of each frame it fuses)",
+                # the kernel sits at its VALU-issue ceiling, not at the HBM one (profiles/: SQ_INSTS_VALU x 4 cycles fills
+                # the launch time); the HBM fraction below is on the bytes a launch has to move
+                "bound": "valu",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
                 "bytes_per_launch": int(bytes_launch),
-                "bytes_per_frame": bytes_frame,
+                "bytes_note": "algorithmic bytes a launch must move: both accumulator plane-sets once (HR*48 B; HR*24 B on the "
+                              "first launch of a burst, which overwrites them), the kernel-parameter field once, raw + flow + "
+                              "certainty of each fused frame; mean over the launches of a burst",
                 "frames_per_launch": round(frames_per_launch, 3),
                 "avg_launch_ms": round(k_ms, 4),
                 "launches_timed": launches.value,
+                "valu": valu,
+                "reference_structure": {
+                    "bytes_per_launch": int(bytes_ref_launch), "achieved": round(achieved_ref, 1),
+                    "frac": round(achieved_ref / HBM_PEAK_GBPS, 4),
+                    "note": "SURVEY.md 8(d) reference-structure bytes (one launch per frame, accumulators RMW per frame) x frames "
+                            "per launch: what the reference's kernel would move for the same frames, NOT what this kernel moves",
+                },
             },
         }
         if not args.no_cpu_baseline and world == 1:

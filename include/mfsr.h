@@ -378,7 +378,10 @@ typedef struct {
     int32_t preAlign;        /* 1: estimate a global base shift + rotation per moved frame (mfsr_preAlign) and feed it to
                                 the tile tracker and the flow field (baseShift / baseRotation of kernel.cu:324, opticalFlow.cu:48) */
     float preAlignMaxAngle;  /* search range of the base rotation in degrees (default 20) */
-    int32_t reserved[3];
+    int32_t uploadRing;      /* > 0: the workspace holds this many device raw-frame slots (>= 3) + 2 reference slots and the
+                                burst owns a copy stream: mfsr_burst_*_host take frames from (pinned) HOST memory and upload
+                                them ahead of the compute (BASELINE configs[4]: double-buffered H2D) */
+    int32_t reserved[2];
 } mfsr_config;
 
 typedef struct mfsr_burst mfsr_burst;
@@ -424,6 +427,18 @@ int mfsr_burst_finish(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float
  * Fused kernels only. */
 int mfsr_burst_finish_rows(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights,
                            mfsr_float3* outImg, uint16_t* out16, int row0, int rows, mfsr_stream_t stream);
+/* ---- bursts whose frames live in HOST memory (cfg.uploadRing > 0).  Same semantics as set_reference / add_frame /
+ * finish, with the H2D copy of every frame enqueued by the library on a copy stream it owns, into a ring of device
+ * slots inside the workspace, so that the upload of frame k+1.. overlaps the align+fuse of frame k (the reference
+ * uploads its frames one blocking copy at a time, multi_frame_sr.cpp:167-174).  hostRaw must stay valid and unchanged
+ * until the stream has passed the call's work; pinned memory (hipHostMalloc) is what makes the copies asynchronous.
+ * add_frame_host(isReference) with the pointer last given to set_reference_host re-uses the uploaded reference. */
+int mfsr_burst_set_reference_host(mfsr_burst* b, const uint16_t* hostRaw, mfsr_stream_t stream);
+int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw, int isReference, mfsr_float3* imgOut,
+                              mfsr_float3* totalWeights, mfsr_stream_t stream);
+/* mfsr_burst_finish into out16Dev (device) followed by its D2H copy into out16Host on the same stream */
+int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights, uint16_t* out16Dev,
+                           uint16_t* out16Host, mfsr_stream_t stream);
 /* HIP-event timing of the warp+fuse (accumulate) launches made by add_frame on
  * the caller's stream: timing(b,1) starts a series, timing_read synchronises with
  * the events and returns the summed kernel milliseconds, the launch count and the

@@ -67,7 +67,8 @@ class Config(ctypes.Structure):
         ("kStretch", ctypes.c_float), ("kShrink", ctypes.c_float),
         ("weightThreshold", ctypes.c_float), ("applyGamma", ctypes.c_int32), ("fused", ctypes.c_int32),
         ("pairFrames", ctypes.c_int32), ("asyncFuse", ctypes.c_int32),
-        ("preAlign", ctypes.c_int32), ("preAlignMaxAngle", ctypes.c_float), ("reserved", ctypes.c_int32 * 3),
+        ("preAlign", ctypes.c_int32), ("preAlignMaxAngle", ctypes.c_float), ("uploadRing", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 2),
     ]
 
 

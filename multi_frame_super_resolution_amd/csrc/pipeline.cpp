@@ -37,6 +37,7 @@ constexpr int kMaxTimedLaunches = 4096;
 // untouched until the warp+fuse that consumes it has run, which with cfg.asyncFuse happens on the
 // burst's own stream while the caller's stream already aligns the next frames.
 constexpr int kRing = 4;
+constexpr int kMaxUploadRing = 16;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -70,6 +71,9 @@ struct Layout {
     // global pre-alignment (cfg.preAlign): search pyramids of the reference and the moved frame, workspace, result
     void *preRefPyr, *preMovPyr, *preWork;
     mfsr_prealign* preResult;
+    // host-frame bursts (cfg.uploadRing): device slots the library uploads into
+    uint16_t* rawRing[kMaxUploadRing];
+    uint16_t* refRaw[2];
     size_t total;
 };
 
@@ -129,6 +133,7 @@ int validate(const mfsr_config* c)
     MFSR_REQUIRE(c->lkIterations >= 0 && c->lkHalfWindow >= 0 && c->lkHalfWindow <= 15);
     MFSR_REQUIRE(c->maxVal > 0);
     if (c->preAlign) MFSR_REQUIRE(c->preAlignMaxAngle >= 0.0f && c->preAlignMaxAngle <= 45.0f);
+    MFSR_REQUIRE(c->uploadRing == 0 || (c->uploadRing >= 3 && c->uploadRing <= kMaxUploadRing));
     return MFSR_OK;
 }
 
@@ -203,6 +208,9 @@ void make_layout(const mfsr_config* c, char* base, Layout* L)
         L->preWork = b.take(mfsr_preAlign_workspace_bytes(c->preAlignMaxAngle));
         L->preResult = (mfsr_prealign*)b.take(sizeof(mfsr_prealign));
     }
+    for (int i = 0; i < c->uploadRing; i++) L->rawRing[i] = (uint16_t*)b.take((size_t)L->W * L->H * 2);
+    if (c->uploadRing > 0)
+        for (int i = 0; i < 2; i++) L->refRaw[i] = (uint16_t*)b.take((size_t)L->W * L->H * 2);
     L->total = align_up(b.off, 256);
 }
 
@@ -250,6 +258,14 @@ struct mfsr_burst {
     hipEvent_t evAligned[kRing];        // recorded on the caller's stream when slot's flow/mask are complete
     hipEvent_t evFused[kRing];          // recorded on fuseStream when the fuse that read the slot is done
     bool fusedOutstanding[kRing];       // evFused[slot] recorded and not yet waited for by the caller's stream
+    // host-frame bursts (cfg.uploadRing): copy stream, per-slot events, reference double buffer
+    hipStream_t copyStream;
+    hipEvent_t evUp[kMaxUploadRing + 2];    // upload of the slot complete (copy stream); [ring..ring+1] = reference slots
+    hipEvent_t evFree[kMaxUploadRing + 2];  // last consumer of the slot enqueued (compute / fuse stream)
+    bool freeRecorded[kMaxUploadRing + 2];
+    int upCounter, refCounter;
+    const uint16_t* refHost;                // host pointer of the current reference and its device copy
+    const uint16_t* refDev;
     // optional per-launch timing of the accumulate kernel (bench.py roofline leg)
     bool timing;
     int nEvents;
@@ -383,6 +399,24 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
             return MFSR_E_NODEVICE;
         }
     }
+    b->copyStream = nullptr;
+    b->upCounter = b->refCounter = 0;
+    b->refHost = b->refDev = nullptr;
+    for (int i = 0; i < kMaxUploadRing + 2; i++) {
+        b->evUp[i] = b->evFree[i] = nullptr;
+        b->freeRecorded[i] = false;
+    }
+    if (cfg->uploadRing > 0) {
+        hipError_t e = hipStreamCreateWithFlags(&b->copyStream, hipStreamNonBlocking);
+        for (int i = 0; i < cfg->uploadRing + 2 && e == hipSuccess; i++) {
+            e = hipEventCreateWithFlags(&b->evUp[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evFree[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) {
+            mfsr_burst_destroy(b);
+            return MFSR_E_NODEVICE;
+        }
+    }
     b->haveRef = false;
     *out = b;
     return MFSR_OK;
@@ -401,6 +435,12 @@ extern "C" void mfsr_burst_destroy(mfsr_burst* b)
         if (b->evFused[i]) (void)hipEventDestroy(b->evFused[i]);
     }
     if (b->fuseStream) (void)hipStreamDestroy(b->fuseStream);
+    if (b->copyStream) (void)hipStreamSynchronize(b->copyStream);
+    for (int i = 0; i < kMaxUploadRing + 2; i++) {
+        if (b->evUp[i]) (void)hipEventDestroy(b->evUp[i]);
+        if (b->evFree[i]) (void)hipEventDestroy(b->evFree[i]);
+    }
+    if (b->copyStream) (void)hipStreamDestroy(b->copyStream);
     delete b;
 }
 
@@ -575,6 +615,17 @@ static int track_tiles(mfsr_burst* b, const mfsr_prealign* hostBase, mfsr_stream
     return MFSR_OK;
 }
 
+// index of the upload slot (ring slot, or ring + i for reference slot i) that raw points to; -1 for caller-owned frames
+static int upload_slot_of(const mfsr_burst* b, const uint16_t* raw)
+{
+    if (!raw) return -1;
+    for (int i = 0; i < b->cfg.uploadRing; i++)
+        if (b->L.rawRing[i] == raw) return i;
+    for (int i = 0; i < 2; i++)
+        if (b->cfg.uploadRing > 0 && b->L.refRaw[i] == raw) return b->cfg.uploadRing + i;
+    return -1;
+}
+
 // G: one or two aligned frames onto the caller's accumulators (timed with HIP events on request)
 static int accumulate_frames(mfsr_burst* b, int n, int slot0, int slot1, const uint16_t* raw0, const uint16_t* raw1,
                              Img* flow0, Img* flow1, Img* mask0, Img* mask1, mfsr_float3* imgOut,
@@ -620,6 +671,17 @@ static int accumulate_frames(mfsr_burst* b, int n, int slot0, int slot1, const u
         MFSR_HIP_TRY(hipEventRecord(b->evStop[b->nEvents], mfsr_s(stream)));
         b->nEvents++;
         b->nFramesTimed += n;
+    }
+    if (b->copyStream) {
+        // upload slots whose raw frame this launch was the last to read may be overwritten once it has run
+        const uint16_t* raws2[2] = {raw0, n == 2 ? raw1 : nullptr};
+        for (int j = 0; j < 2; j++) {
+            const int us = upload_slot_of(b, raws2[j]);
+            if (us >= 0) {
+                MFSR_HIP_TRY(hipEventRecord(b->evFree[us], mfsr_s(stream)));
+                b->freeRecorded[us] = true;
+            }
+        }
     }
     if (b->fuseStream) {
         MFSR_HIP_TRY(hipEventRecord(b->evFused[slot0], b->fuseStream));
@@ -830,6 +892,58 @@ extern "C" int mfsr_burst_finish_rows(mfsr_burst* b, const mfsr_float3* imgOut, 
                             outImg ? (mfsr_float3*)((char*)outImg + off) : nullptr, pitch,
                             out16 ? out16 + (size_t)row0 * L.hrW * 3 : nullptr, L.hrW, rows, c.weightThreshold,
                             c.applyGamma, 65535.0f, stream);
+}
+
+// ---- host-frame bursts (cfg.uploadRing) --------------------------------------------------------------------------
+// enqueue the upload of hostRaw into upload slot `us` on the copy stream (after the slot's last consumer) and make the
+// compute stream wait for it
+static int upload_into(mfsr_burst* b, int us, uint16_t* dst, const uint16_t* hostRaw, mfsr_stream_t stream)
+{
+    if (b->freeRecorded[us]) {
+        MFSR_HIP_TRY(hipStreamWaitEvent(b->copyStream, b->evFree[us], 0));
+        b->freeRecorded[us] = false;
+    }
+    MFSR_HIP_TRY(hipMemcpyAsync(dst, hostRaw, (size_t)b->L.W * b->L.H * 2, hipMemcpyHostToDevice, b->copyStream));
+    MFSR_HIP_TRY(hipEventRecord(b->evUp[us], b->copyStream));
+    MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evUp[us], 0));
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_burst_set_reference_host(mfsr_burst* b, const uint16_t* hostRaw, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && hostRaw);
+    MFSR_REQUIRE(b->copyStream != nullptr);  // cfg.uploadRing > 0
+    TRY(flush_pending(b, stream, false));    // a frame still waiting reads the previous reference's slots
+    const int i = b->refCounter++ & 1;
+    const int us = b->cfg.uploadRing + i;
+    // the slot's previous reference (two bursts ago) was last read by work already enqueued on the compute stream
+    MFSR_HIP_TRY(hipEventRecord(b->evFree[us], mfsr_s(stream)));
+    b->freeRecorded[us] = true;
+    TRY(upload_into(b, us, b->L.refRaw[i], hostRaw, stream));
+    b->refHost = hostRaw;
+    b->refDev = b->L.refRaw[i];
+    return mfsr_burst_set_reference(b, b->refDev, stream);
+}
+
+extern "C" int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw, int isReference, mfsr_float3* imgOut,
+                                         mfsr_float3* totalWeights, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && hostRaw && imgOut && totalWeights);
+    MFSR_REQUIRE(b->copyStream != nullptr);
+    if (isReference && hostRaw == b->refHost && b->refDev)
+        return mfsr_burst_add_frame(b, b->refDev, 1, imgOut, totalWeights, stream);
+    const int us = b->upCounter++ % b->cfg.uploadRing;
+    TRY(upload_into(b, us, b->L.rawRing[us], hostRaw, stream));
+    return mfsr_burst_add_frame(b, b->L.rawRing[us], isReference, imgOut, totalWeights, stream);
+}
+
+extern "C" int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights,
+                                      uint16_t* out16Dev, uint16_t* out16Host, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && out16Dev && out16Host);
+    TRY(mfsr_burst_finish(b, imgOut, totalWeights, nullptr, out16Dev, stream));
+    MFSR_HIP_TRY(hipMemcpyAsync(out16Host, out16Dev, (size_t)b->L.hrW * b->L.hrH * 6, hipMemcpyDeviceToHost, mfsr_s(stream)));
+    return MFSR_OK;
 }
 
 extern "C" int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2d* mask, mfsr_tex2d* kernelParam,

@@ -122,6 +122,32 @@ class BurstPipeline:
             self.add_frame(frames[k], k == ref)
         return self.finish()
 
+    # ---- frames in (pinned) host memory: the library uploads them on its own copy stream (cfg.uploadRing > 0) ----
+    def process_host(self, host_frames: Sequence[torch.Tensor], out16_host: Optional[torch.Tensor] = None):
+        """Whole burst from HOST frames (pin them: ``t.pin_memory()``) to the u16 HR image in host memory:
+        mfsr_burst_set_reference_host / add_frame_host / finish_host.  Returns the (pinned) host image; it is complete
+        once the current stream has been synchronised."""
+        if self.cfg.uploadRing <= 0:
+            raise ValueError("cfg.uploadRing must be > 0 for host-frame bursts")
+        for f in host_frames:
+            if f.is_cuda or f.dtype not in (torch.int16, torch.uint16) or not f.is_contiguous() or \
+                    tuple(f.shape) != (self.cfg.height, self.cfg.width):
+                raise ValueError("host frames must be contiguous 16-bit CPU tensors of the configured size")
+        if out16_host is None:
+            if getattr(self, "_out16_host", None) is None:
+                self._out16_host = torch.empty(self.hr_h, self.hr_w, 3, dtype=torch.int16).pin_memory()
+            out16_host = self._out16_host
+        st = self._stream()
+        self.begin_burst()
+        ref = self.cfg.reference
+        self.L.burst_set_reference_host(self._h, host_frames[ref].data_ptr(), st)
+        for k, f in enumerate(host_frames):
+            self.L.burst_add_frame_host(self._h, f.data_ptr(), 1 if k == ref else 0, self._img_out.data_ptr(),
+                                        self._total_weights.data_ptr(), st)
+        self.L.burst_finish_host(self._h, self._img_out.data_ptr(), self._total_weights.data_ptr(), self.out16.data_ptr(),
+                                 out16_host.data_ptr(), st)
+        return out16_host
+
     def process_stream(self, frames: Sequence[torch.Tensor], radius: int = 1):
         """Sliding-window ("temporal area radius", reference multi_frame_sr.cpp:182) use of the burst path:
         output t fuses frames [t-radius, t+radius] (clipped to the stream) with frame t as the reference.

@@ -55,14 +55,33 @@ def _shifted(scene: torch.Tensor, tx: float, ty: float) -> torch.Tensor:
     return (1 - fx) * (1 - fy) * s + fx * (1 - fy) * s10 + (1 - fx) * fy * s01 + fx * fy * s11
 
 
+def _rotated(scene: torch.Tensor, tx: float, ty: float, angle_deg: float) -> torch.Tensor:
+    """scene sampled at c + R(angle) (p - c) + (tx, ty), bilinear, c = image centre (the rotation stress variant of
+    SURVEY.md section 8d; the reference's generator rotates its crops the same way, test_opencv/main.cpp:1896-1907)."""
+    _, h, w = scene.shape
+    a = math.radians(angle_deg)
+    ca, sa = math.cos(a), math.sin(a)
+    dev = scene.device
+    yy, xx = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32), torch.arange(w, device=dev, dtype=torch.float32),
+                            indexing="ij")
+    cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+    dx, dy = xx - cx, yy - cy
+    qx = cx + ca * dx - sa * dy + tx
+    qy = cy + sa * dx + ca * dy + ty
+    grid = torch.stack([(qx + 0.5) / w * 2 - 1, (qy + 0.5) / h * 2 - 1], -1)[None]
+    return F.grid_sample(scene[None], grid, mode="bilinear", padding_mode="border", align_corners=False)[0]
+
+
 def make_burst(width: int, height: int, frames: int, scale: int = 2, mono: bool = False, seed: int = 1234,
                device="cpu", max_shift: float = 5.0, noise: bool = True, alpha: float = 1e-4, beta: float = 1e-6,
                black: float = 256.0, white: float = 4095.0 - 256.0, shift_seed: Optional[int] = None,
-               first_is_reference: bool = True) -> Tuple[List[torch.Tensor], torch.Tensor, torch.Tensor]:
+               first_is_reference: bool = True,
+               angles_deg: Optional[List[float]] = None) -> Tuple[List[torch.Tensor], torch.Tensor, torch.Tensor]:
     """Returns (raw frames [H,W] int16 holding u16 bit patterns, shifts [N,2] in LR px, ground truth [3,sH,sW]).
 
     ``seed`` fixes the scene; ``shift_seed`` (default: same stream) fixes the per-frame shifts and
-    noise, so ranks of a sharded burst can draw different frames of the SAME scene."""
+    noise, so ranks of a sharded burst can draw different frames of the SAME scene.  ``angles_deg`` (one per frame)
+    additionally rotates frame k about the frame centre (needs cfg.preAlign beyond a degree or two)."""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     s = scale
@@ -80,7 +99,9 @@ def make_burst(width: int, height: int, frames: int, scale: int = 2, mono: bool 
     cfa_idx = ((yy % 2) + (xx % 2))  # RGGB: (0,0)->R=0, (0,1)/(1,0)->G=1, (1,1)->B=2
     for k in range(frames):
         tx, ty = float(shifts[k, 0]) * s, float(shifts[k, 1]) * s
-        sh = _shifted(scene, tx, ty)[:, m:m + s * height, m:m + s * width]
+        ang = float(angles_deg[k]) if angles_deg is not None else 0.0
+        full = _shifted(scene, tx, ty) if ang == 0.0 else _rotated(scene, tx, ty, ang)
+        sh = full[:, m:m + s * height, m:m + s * width]
         lr = F.avg_pool2d(sh[None], s)[0] if s > 1 else sh
         if noise:
             lr = lr + torch.randn(lr.shape, generator=gen, device=device) * torch.sqrt(alpha * lr + beta)

@@ -95,7 +95,7 @@ class OraclePipeline:
         o.deBayerGreenKernel(self.W, self.H, rawf, _pitch(rawf), self.fallback, _pitch(self.fallback), self.black, scale)
         o.deBayerRedBlueKernel(self.W, self.H, rawf, _pitch(rawf), self.fallback, _pitch(self.fallback), self.black, scale)
 
-    def _track(self, mov_pyr):
+    def _track(self, mov_pyr, base=(0.0, 0.0, 0.0)):
         o, c = self.o, self.c
         shifts = None
         for l in range(c.levels):
@@ -119,7 +119,9 @@ class OraclePipeline:
             dist = np.zeros((n, R, R), np.float32)
             found = np.zeros((tcy, tcx, 2), np.float32)
             o.convertToTilesOverlapBorder(ref, rt, lw, lh, _pitch(ref), S, T, tcx, tcy, 0.0, 0.0, 0.0)
-            o.convertToTilesOverlapPreShift(mov, mt, pre, _pitch(pre), lw, lh, _pitch(mov), S, T, tcx, tcy, 0.0, 0.0, 0.0)
+            inv = np.float32(1.0) / np.float32(c.levelFactor[l])   # base shift in pixels of this pyramid level
+            o.convertToTilesOverlapPreShift(mov, mt, pre, _pitch(pre), lw, lh, _pitch(mov), S, T, tcx, tcy,
+                                            float(np.float32(base[0]) * inv), float(np.float32(base[1]) * inv), float(base[2]))
             o.crossCorrelateTiles(rt, mt, cc, S, T, n)
             o.squaredSum(rt, sq, S, T, n)
             o.boxFilterWithBorderX(mt, bx, S, T, n)
@@ -138,11 +140,21 @@ class OraclePipeline:
             mask = np.ones((self.hh, self.hw, 4), np.float32)
         else:
             mov_half, mov_pyr = self._prepare(raw)
-            shifts = self._track(mov_pyr)
+            base = (0.0, 0.0, 0.0)
+            if getattr(c, "preAlign", 0):
+                # I: global pre-alignment (oracle/prealign.c) -> baseShift / baseRotation of B2 and D1
+                res = np.zeros(5, np.float32)
+                st = np.zeros(4, np.int32)
+                o.preAlign(self.ref_pyr[0], mov_pyr[0], self.tw, self.th, _pitch(self.ref_pyr[0]), float(c.preAlignMaxAngle),
+                           res, st)
+                base = (float(res[0]), float(res[1]), float(res[2]))
+                self.prealign = dict(shift=(float(res[0]), float(res[1])), rotation=float(res[2]), angle_index=int(st[0]),
+                                     t=(int(st[1]), int(st[2])), level=int(st[3]))
+            shifts = self._track(mov_pyr, base)
             tcx, tcy = self.tc[-1]
             flow = np.zeros((self.th, self.tw, 2), np.float32)
             o.CreateFlowFieldFromTiles(flow, shifts, _pitch(shifts), tcx, tcy, c.tileSize[c.levels - 1], tcx, tcy,
-                                       self.tw, self.th, _pitch(flow), 0.0, 0.0, 0.0)
+                                       self.tw, self.th, _pitch(flow), base[0], base[1], base[2])
             ref0, mov0 = self.ref_pyr[0], mov_pyr[0]
             warped = np.zeros_like(ref0)
             Ix, Iy, It = np.zeros_like(ref0), np.zeros_like(ref0), np.zeros_like(ref0)

@@ -49,3 +49,35 @@ def test_cli_city_burst(tmp_path):
     print("CLI x2 result PSNR vs scene:", psnr)
     assert psnr > 24.0
     assert (out2[0] == 0).all() and (out2[:, 0] == 0).all()                      # sharpenImg2 zeroes the ring (:114-117)
+
+
+@pytest.mark.gpu
+def test_cli_on_the_bundled_city_frames(tmp_path):
+    """The CLI on the reference's own data (tests/golden/city = test_opencv/img_00000[0-4].png, 0-based names): its 8-bit
+    result is exactly what the Python host gets from the same library with the same configuration (whose parity with
+    the oracle tests/test_bundled_burst.py asserts), so all five frames -- including the rotated ones -- are fused."""
+    import ctypes
+    import shutil
+    import torch
+    from PIL import Image
+    from multi_frame_super_resolution_amd.pipeline import BurstPipeline
+    from tests.test_bundled_burst import CITY, _cfg, _raws
+    assert os.path.exists(CLI), "build apps/multi_frame_sr first (__graft_entry__.build())"
+    for i in range(5):
+        shutil.copy(os.path.join(CITY, f"img_{i:06d}.png"), tmp_path / f"img_{i:06d}.png")
+    p = subprocess.run([CLI, "farneback", "city", "3"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "img_000000.png, [512 x 256]" in p.stdout and "img_000004.png, [512 x 256]" in p.stdout
+    out = np.asarray(Image.open(tmp_path / "city_farneback_sr_result.png"))
+    raws, W, H = _raws(5)
+    cfg = _cfg(W, H, 5)
+    cfg.preAlign = 1
+    cfg.lkIterations = 3
+    dev = torch.device("cuda:0")
+    pipe = BurstPipeline(cfg, dev)
+    res, _ = pipe.process([torch.from_numpy(r.view(np.int16)).to(dev) for r in raws])
+    q = torch.empty(2 * H, 2 * W, 3, dtype=torch.uint8, device=dev)
+    pipe.L.quantize(res.data_ptr(), 12 * 2 * W, None, q.data_ptr(), 2 * W, 2 * H, 255.0, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(q.cpu().numpy(), out)
+    pipe.close()

@@ -313,3 +313,20 @@ def test_robustness_mask_limits(orc):
     uv2[:, (np.arange(W) % 4) < 2, 0] = 6.0   # flow(x) != flow(x+2): the only pair the quirk compares (:62-72)
     orc.call("ComputeRobustnessMask", ref, ref + 0.3, mask, Tex(uv2), W, H, pitch_of(ref), pitch_of(mask), 1e-4, 1e-6, 0.1)
     assert (mask[1:-1, 1:-3, :3] == 0.0).all() and (mask[1:-1, 1:-3, 3] > 0.1).all()
+
+
+@pytest.mark.parametrize("angle,tx,ty", [(5.0, 1.0, 3.0), (-15.0, -4.0, 2.0), (0.0, 0.0, 0.0), (10.0, 6.0, -6.0)])
+def test_prealign_recovers_a_known_rotation(angle, tx, ty):
+    """Known answer for the global pre-alignment (oracle/prealign.c): a scene re-sampled under the model
+    q = c + R(theta)(p - c - t) comes back with theta to < 0.2 degree and t to the search grid of the finest level."""
+    from oracle.bindings import oracle
+    from tests.test_parity_kernels import _rotated_pair
+    W, H = 512, 256
+    ref, mov = _rotated_pair(W, H, angle, tx, ty, 7)
+    res = np.zeros(5, np.float32)
+    st = np.zeros(4, np.int32)
+    n = oracle().preAlign(ref, mov, W, H, ref.strides[0], 20.0, res, st)
+    assert n == 4 and st[3] == 0                      # 512 -> 256 -> 128 -> 64: four levels, finest = the image itself
+    assert abs(np.degrees(res[2]) - angle) < 0.2
+    assert abs(res[0] - tx) <= 1.0 and abs(res[1] - ty) <= 1.0
+    assert res[3] == np.cos(np.float32(res[2]), dtype=np.float32) or abs(res[3] - np.cos(res[2])) < 1e-6

@@ -1042,3 +1042,57 @@ def test_gaussin_filter_1D_host(orc, hip):
         n2 = hip.L.gaussin_filter_1D(sigma, t2)
         assert n1 == n2
         np.testing.assert_array_equal(t1[:n1], np.array(t2[:n2], np.float32))
+
+
+# ---- global pre-alignment (csrc/prealign.hip vs oracle/prealign.c): integer scores -> identical results ----------
+def _rotated_pair(W, H, angle_deg, tx, ty, seed):
+    """A smooth random image and the same scene sampled at c + R(angle)(p - c - t) (what the model says the moved
+    frame shows at reference pixel p)."""
+    from scipy import ndimage
+    r = rng(seed)
+    big = ndimage.gaussian_filter(r.random((H + 200, W + 200)), 2.0)
+    big = ((big - big.min()) / (big.max() - big.min())).astype(np.float32)
+    big += 0.25 * (ndimage.gaussian_filter(r.random(big.shape), 8.0) > 0.5)
+    big = (big / big.max()).astype(np.float32)
+    ref = np.ascontiguousarray(big[100:100 + H, 100:100 + W])
+    a = np.radians(angle_deg)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    cx, cy = W // 2, H // 2
+    # moved(q) = scene(p) with q = c + R(p - c - t)  <=>  p = c + t + R^-1 (q - c)
+    dx, dy = xx - cx, yy - cy
+    px = cx + tx + np.cos(a) * dx + np.sin(a) * dy
+    py = cy + ty - np.sin(a) * dx + np.cos(a) * dy
+    mov = ndimage.map_coordinates(big, [py + 100, px + 100], order=1, mode="nearest").astype(np.float32)
+    return ref, np.ascontiguousarray(mov)
+
+
+@pytest.mark.parametrize("W,H,angle,tx,ty", [(256, 128, 7.0, 3.0, -2.0), (200, 150, -12.5, -5.0, 4.0), (96, 64, 0.0, 1.0, 1.0),
+                                             (1300, 700, 3.3, 20.0, -11.0)])
+def test_preAlign_matches_oracle_exactly(orc, hip, W, H, angle, tx, ty):
+    import torch
+    ref, mov = _rotated_pair(W, H, angle, tx, ty, 91)
+    res = np.zeros(5, np.float32)
+    st = np.zeros(4, np.int32)
+    n = orc.o.preAlign(ref, mov, W, H, pitch_of(ref), 20.0, res, st)
+    assert n >= 1
+    assert abs(np.degrees(res[2]) - angle) <= 0.6   # the grid step of the finest searched level is <= 0.5 degree
+    L = hip.L
+    dev = hip.dev
+    pb = L.preAlign_pyramid_bytes(W, H)
+    wb = L.preAlign_workspace_bytes(20.0)
+    assert pb > 0 and wb > 0
+    bufs = [torch.zeros(x + 256, dtype=torch.uint8, device=dev) for x in (pb, pb, wb, 256)]
+    ptr = [(b.data_ptr() + 255) // 256 * 256 for b in bufs]
+    dref, dmov = torch.from_numpy(ref).to(dev), torch.from_numpy(mov).to(dev)
+    L.preAlign_init(ptr[2], 20.0, None)
+    L.preAlignPyramid(dref.data_ptr(), W, H, pitch_of(ref), ptr[0], None)
+    L.preAlignPyramid(dmov.data_ptr(), W, H, pitch_of(mov), ptr[1], None)
+    for _ in range(2):   # a second search on the same workspace starts from clean scores
+        L.preAlign(ptr[0], ptr[1], W, H, 20.0, ptr[2], ptr[3], None)
+    torch.cuda.synchronize()
+    off = ptr[3] - bufs[3].data_ptr()
+    raw = bufs[3][off:off + 48].cpu().numpy()
+    f = raw[:20].view(np.float32)
+    i = raw[20:36].view(np.int32)
+    assert tuple(i) == tuple(st), (i, st)
+    assert_bitexact(f, res, "preAlign result")
