@@ -144,8 +144,14 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="4k16_rggb_x2", choices=list(WORKLOADS))
-    ap.add_argument("--strong", action="store_true", help="fixed 16-frame burst sharded over the GPUs")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "reduce", "reduce_scatter"])
+    ap.add_argument("--strong", action="store_true", help="(default at N > 1) the workload's fixed burst sharded over the GPUs")
+    ap.add_argument("--weak", action="store_true", help="N > 1: frames-per-GPU x N frames in one burst (per-GPU alignment work fixed)")
+    ap.add_argument("--exchange", default="stripes", choices=["stripes", "auto", "reduce", "reduce_scatter"],
+                    help="N > 1: stripes (default: p2p exchange of LR products, fuse sharded over HR row stripes, bit-identical "
+                         "to 1 GPU), reduce (north_star's wording: accumulators onto rank 0), reduce_scatter")
+    ap.add_argument("--dist-impl", default="rccl", choices=["rccl", "torch"],
+                    help="N > 1: rccl = the C-ABI multi-GPU layer (libmfsr_dist.so, RCCL directly); torch = its torch.distributed "
+                         "mirror (distributed.py; also what MFSR_DIST_BACKEND=gloo rehearsals use)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the H2D->D2H end-to-end leg (median of 20 bursts)")
     ap.add_argument("--cpu-sample-frames", type=int, default=4)
@@ -196,7 +202,8 @@ def main():
     from multi_frame_super_resolution_amd.synth import make_burst
 
     W, H, fpg, s, mono = WORKLOADS[args.workload]
-    n_frames = fpg if args.strong else fpg * world
+    strong = not args.weak           # N > 1: the workload's burst is fixed and sharded (north_star: ">= 6x at 8 GPUs vs 1")
+    n_frames = fpg if strong else fpg * world
     cfg = default_config(W, H, n_frames, s, mono)
     cfg.fused = 0 if args.unfused else 1
     if args.no_pair:
@@ -205,7 +212,10 @@ def main():
         cfg.asyncFuse = 1
     if world == 1:
         cfg.uploadRing = 4      # device slots for --h2d and the end-to-end leg (mfsr_burst_*_host); unused by the resident run
-    pipe = BurstPipeline(cfg, dev)
+    exchange = "stripes" if args.exchange == "auto" else args.exchange
+    dist_impl = "torch" if backend == "gloo" else args.dist_impl
+    use_cabi_dist = world > 1 and dist_impl == "rccl"
+    pipe = None if use_cabi_dist else BurstPipeline(cfg, dev)
 
     # synthetic burst: one scene (same seed on every rank), this rank's frames only
     seed = 1234 + 2
@@ -218,12 +228,39 @@ def main():
     del shard
     torch.cuda.synchronize()
 
-    # Steps are independent bursts, so at N>1 the exchange (reduce-scatter, stripe finish, gather)
-    # of burst i runs on a side stream while the compute stream already aligns and fuses burst
-    # i+1 into a second burst context (own workspace + accumulators): collectives overlap compute.
-    pipelined = (world > 1 and not args.no_overlap) or args.force_pipelined
-    pipes = [pipe]
+    # N > 1, C-ABI path: one mfsr_dist context per rank (RCCL communicator + burst context + per-frame product buffers);
+    # a step is one mfsr_dist_process_burst on the current stream
+    dctx = None
+    if use_cabi_dist:
+        from multi_frame_super_resolution_amd import capi
+        D = capi.dist_lib()
+        uid = torch.zeros(capi.DIST_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            buf = (ctypes.c_uint8 * capi.DIST_ID_BYTES)()
+            D.dist_get_unique_id(buf)
+            uid = torch.tensor(list(buf), dtype=torch.uint8)
+        uid = uid.to(dev)
+        dist.broadcast(uid, src=0)
+        uid_c = (ctypes.c_uint8 * capi.DIST_ID_BYTES)(*uid.cpu().tolist())
+        nbytes = D.dist_workspace_bytes(ctypes.byref(cfg), world)
+        d_ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        d_h = ctypes.c_void_p()
+        D.dist_create(ctypes.byref(d_h), ctypes.byref(cfg), rank, world, uid_c, (d_ws.data_ptr() + 255) // 256 * 256, nbytes)
+        d_out16 = torch.empty(H * s, W * s, 3, dtype=torch.int16, device=dev) if rank == 0 else None
+        d_status = torch.zeros(1, dtype=torch.int32, device=dev)
+        d_ptrs = (ctypes.c_void_p * n_frames)(*[frames[k].data_ptr() if k in frames else None for k in range(n_frames)])
+        d_mode = {"stripes": capi.DIST_STRIPES, "reduce": capi.DIST_REDUCE, "reduce_scatter": capi.DIST_REDUCE_SCATTER}[exchange]
+        dctx = dict(D=D, h=d_h, burst=D.dist_burst(d_h))
+
+    # torch.distributed mirror, accumulator-summing modes: steps are independent bursts, so the exchange (reduce-scatter,
+    # stripe finish, gather) of burst i runs on a side stream while the compute stream already aligns and fuses burst i+1
+    # into a second burst context (own workspace + accumulators): collectives overlap compute.
+    pipelined = ((world > 1 and not args.no_overlap and not use_cabi_dist and exchange != "stripes") or args.force_pipelined)
+    pipes = [pipe] if pipe is not None else []
     step_no = [0]
+    stripe_bufs = None
+    if world > 1 and not use_cabi_dist and exchange == "stripes":
+        stripe_bufs = mdist.StripeBuffers(pipe, n_frames, rank, world)
     if pipelined:
         pipes.append(BurstPipeline(cfg, dev))
         side = torch.cuda.Stream(device=dev)
@@ -245,10 +282,16 @@ def main():
     def step():
         if h2d:
             return step_h2d()
+        if use_cabi_dist:
+            D.dist_process_burst(d_h, d_ptrs, d_mode, d_out16.data_ptr() if d_out16 is not None else None, d_status.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+            return d_out16
+        if stripe_bufs is not None:
+            return mdist.process_burst_stripes(pipe, frames, stripe_bufs, n_frames=n_frames)[0]
         if not pipelined:
             if world > 1:
                 mdist.accumulate_local(pipe, frames, rank, world, n_frames)
-                return mdist.exchange_and_finish(pipe, args.exchange)
+                return mdist.exchange_and_finish(pipe, exchange)
             return mdist.process_burst(pipe, frames, n_frames=n_frames)
         j = step_no[0] % 2
         step_no[0] += 1
@@ -261,7 +304,7 @@ def main():
         with torch.cuda.stream(side):
             side.wait_event(ev_acc[j])
             if world > 1:
-                out = mdist.exchange_and_finish(p, args.exchange)
+                out = mdist.exchange_and_finish(p, exchange)
             else:
                 _, out = p.finish(want_float=False, want_u16=True)
             ev_done[j].record(side)
@@ -278,18 +321,35 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    for q in pipes:
-        q.L.burst_timing(q._h, 1)
+    halo_note = None
+    if use_cabi_dist and exchange == "stripes":
+        # a vertical flow beyond the raw halo of the stripes exchange (status 1) invalidates the result: exchange whole raw
+        # frames instead (always valid, ~2.5x the traffic); decided on a probe burst outside the timed region
+        if args.warmup == 0:
+            step()
+            barrier()
+        st = d_status.clone()
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        if int(st.item()) != 0:
+            D.dist_set_raw_halo(d_h, H)
+            halo_note = "whole raw frames exchanged (a flow exceeded the default 64-row halo)"
+            step()
+            barrier()
+    from multi_frame_super_resolution_amd import capi as _capi
+    LIB = _capi.lib()
+    timed_bursts = [q._h for q in pipes] + ([dctx["burst"]] if dctx else [])
+    for hb in timed_bursts:
+        LIB.burst_timing(hb, 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
     tot_ms, launches, fused_frames = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_int(0)
-    for q in pipes:
+    for hb in timed_bursts:
         t_ms, n_l, n_f = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_int(0)
-        q.L.burst_timing_read(q._h, ctypes.byref(t_ms), ctypes.byref(n_l), ctypes.byref(n_f))
-        q.L.burst_timing(q._h, 0)
+        LIB.burst_timing_read(hb, ctypes.byref(t_ms), ctypes.byref(n_l), ctypes.byref(n_f))
+        LIB.burst_timing(hb, 0)
         tot_ms.value += t_ms.value
         launches.value += n_l.value
         fused_frames.value += n_f.value
@@ -298,6 +358,9 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if use_cabi_dist and int(d_status.item()) != 0:
+        raise SystemExit("mfsr_dist: a frame's vertical flow exceeded the raw halo of the stripes exchange (status 1): the result is "
+                         "invalid; use --exchange reduce_scatter or a larger halo")
 
     # SURVEY.md section 8(d)'s end-to-end figure, beside the HBM-resident `value`: wall time from the first H2D enqueue
     # to the final D2H complete, one burst at a time, median of 20 (after 5 warm-up bursts)
@@ -325,10 +388,19 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = n_frames * W * H * args.steps / dt / 1e6
         # bytes a launch MUST move (accumulators once per launch, not once per frame) vs the reference-structure figure
-        n_launch_burst, bytes_burst = burst_fuse_bytes(W, H, s, mono, len(mine), bool(cfg.pairFrames))
-        bytes_launch = bytes_burst / n_launch_burst
+        # frames fused per rank and the fraction of the HR rows a launch covers: all frames on 1/world of the rows in the
+        # stripes mode, the rank's own frames on the whole grid otherwise
+        stripes_mode = world > 1 and exchange == "stripes"
+        fused_per_rank = n_frames if stripes_mode else len(mine)
+        row_frac = 1.0
+        if stripes_mode:
+            pl = _capi.StripePlan()
+            LIB.dist_stripe_plan(ctypes.byref(cfg), world, 0, 64, ctypes.byref(pl))
+            row_frac = (pl.rowEnd - pl.rowBegin) / float(H * s)
+        n_launch_burst, bytes_burst = burst_fuse_bytes(W, H, s, mono, fused_per_rank, bool(cfg.pairFrames))
+        bytes_launch = bytes_burst / n_launch_burst * row_frac
         frames_per_launch = fused_frames.value / max(launches.value, 1)
-        bytes_ref_launch = fuse_bytes_reference_structure(W, H, s, mono) * frames_per_launch
+        bytes_ref_launch = fuse_bytes_reference_structure(W, H, s, mono) * frames_per_launch * row_frac
         k_ms = tot_ms.value / max(launches.value, 1)
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         achieved_ref = bytes_ref_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
@@ -360,7 +432,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "strong" if args.strong else "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" + (", streamed from pinned host memory (library copy stream, 4-slot device ring)" if h2d else
@@ -371,8 +443,13 @@ def main():
                 "frames_per_gpu": len(mine),
                 "burst_frames": n_frames,
                 "output_mpix_per_s": round(s * s * W * H * args.steps / dt / 1e6, 2),
-                "parallelism": "1 GPU" if world == 1 else f"frame-shard x{world} + RCCL {args.exchange} of HR accumulators"
-                               + (" overlapped with the next burst's compute" if pipelined else ""),
+                "parallelism": "1 GPU" if world == 1 else (
+                    (f"align frame-sharded x{world}, p2p exchange of the LR products (raw/flow/certainty rows), fuse sharded over "
+                     f"{world} HR row stripes, u16 stripes gathered on rank 0 (bit-identical to 1 GPU)" if exchange == "stripes" else
+                     f"frame-shard x{world} + RCCL {exchange} of the HR accumulators"
+                     + (" overlapped with the next burst's compute" if pipelined else ""))
+                    + (", libmfsr_dist.so (RCCL directly)" if use_cabi_dist else ", torch.distributed mirror")
+                    + (f"; {halo_note}" if halo_note else "")),
                 "kernels": "unfused (one launch per reference kernel)" if args.unfused else "fused",
                 **({"rehearsal": "gloo backend, ranks share GPUs, collectives staged through the host: not a measurement"}
                    if (world > 1 and backend == "gloo") else {}),
@@ -413,6 +490,8 @@ def main():
 
     for q in pipes:
         q.close()
+    if dctx:
+        dctx["D"].dist_destroy(dctx["h"])
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

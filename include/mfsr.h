@@ -127,6 +127,16 @@ int mfsr_accumulateSuperResFullN(int nFrames, const uint16_t* const* dataIn, mfs
                                  mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int scale,
                                  int strideOut, int strideMask, int accumulatorsUndefined, mfsr_stream_t stream);
 
+/* mfsr_accumulateSuperResFullN restricted to HR rows [rowBegin, rowEnd) (rowBegin % 16 == 0; rowEnd % 16 == 0 or
+ * rowEnd == scale*dimY): a burst whose fuse stage is sharded over HR row stripes (multi-GPU, mfsr_dist_*) calls it once
+ * per stripe; every pixel of the window gets exactly the whole-frame result.  Raw / certainty / shift buffers keep their
+ * whole-frame addressing -- only the rows the window's taps reach are read. */
+int mfsr_accumulateSuperResFullRows(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                                    const mfsr_float4* const* certaintyMask, mfsr_tex2d kernelParam, const mfsr_tex2d* shifts,
+                                    mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int scale,
+                                    int strideOut, int strideMask, int accumulatorsUndefined, int rowBegin, int rowEnd,
+                                    mfsr_stream_t stream);
+
 /* ---- B/E/H/I: kernel.cu --------------------------------------------------- */
 int mfsr_squaredSum(const float* inTiles, float* outValues, int maxShift, int tileSize, int tileCount,
                     mfsr_stream_t stream); /* :119 */
@@ -199,6 +209,12 @@ int mfsr_solveShiftsBatched(const float* shiftMatrix, const mfsr_float2* measure
 int mfsr_minimizeShifts(float* shiftMatrix, mfsr_float2* measuredShifts, mfsr_float2* shiftsOneToOne,
                         float* optimShiftsT, int* status, int* inversionInfo, int tileCount, int imageCount,
                         int shiftCount, int* roundsOut, mfsr_stream_t stream);
+
+/* the same loop inside one launch (the tiles are independent: one wavefront per tile iterates solve -> checkForOutliers
+ * until its tile converges): no host synchronisation, graph-capturable, bit-identical to mfsr_minimizeShifts */
+int mfsr_minimizeShiftsFused(float* shiftMatrix, mfsr_float2* measuredShifts, mfsr_float2* shiftsOneToOne, float* optimShiftsT,
+                             int* status, int* inversionInfo, int tileCount, int imageCount, int shiftCount,
+                             mfsr_stream_t stream);
 
 /* ---- D/E: opticalFlow.cu -------------------------------------------------- */
 /* texUV: CLAMP; texToWarp: MIRROR */
@@ -294,6 +310,13 @@ int mfsr_tileSquaredSums(const float* refImg, float* outValues, int imgWidth, in
 int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_float2* shiftsOut, int pitchShift,
                                    const float* refImg, const float* movedImg, int pitchImg, int width, int height,
                                    int halfWindowSize, float minDet, float outScale, mfsr_stream_t stream);
+/* F1 (ComputeRobustnessMask, RobustnessModell.cu:29) + its zero ring (:48-49) in one launch: reference patch through an
+ * LDS tile, hardware sqrt / rcp / exp (mask within 2e-6 of the straight kernel; the roundings and the M threshold keep
+ * their exact arithmetic).  mfsr_set_robustness_fast(0) routes it to ring + mfsr_ComputeRobustnessMask. */
+int mfsr_robustnessMaskFused(const mfsr_float3* rawImgRef, const mfsr_float3* rawImgMoved, mfsr_float4* robustnessMask,
+                             mfsr_tex2d texUV, int imgWidth, int imgHeight, int imgPitch, int maskPitch, float alpha, float beta,
+                             float thresholdM, mfsr_stream_t stream);
+int mfsr_set_robustness_fast(int enable);
 /* E1+E2 (derivatives + structure tensor) in one launch */
 int mfsr_structureTensorFused(const float* img, int imgPitch, mfsr_float3* outImg, int outPitch, int width, int height,
                               mfsr_stream_t stream);
@@ -340,6 +363,13 @@ int mfsr_trackTilesFusedBase(const float* refImg, const float* movedImg, const m
 /* mfsr_CreateFlowFieldFromTiles (opticalFlow.cu:48) with baseShift / baseRotation taken from *base (device) */
 int mfsr_CreateFlowFieldFromTilesBase(mfsr_float2* outImg, mfsr_tex2d texObjShiftXY, int imgWidth, int imgHeight,
                                       int imgPitch, const mfsr_prealign* base, mfsr_stream_t stream);
+
+/* mfsr_finishFused on rows [rowOffset, rowOffset + height) of a fullHeight-row image (pointers = first row of the stripe;
+ * u/v window = that of the WHOLE image): bit-identical to the rows of the whole-image call */
+int mfsr_finishFusedRows(const mfsr_float3* finalImg, const mfsr_float3* weight, int imgPitch, const mfsr_float3* fallback,
+                         int fbPitch, int fbW, int fbH, float u0, float u1, float v0, float v1, mfsr_float3* outImg,
+                         int outPitch, uint16_t* out16, int width, int height, float threshold, int applyGamma, float maxOut,
+                         int rowOffset, int fullHeight, mfsr_stream_t stream);
 
 /* ---- burst pipeline (the L3 driver the reference lacks; mirrors the CLI
  *      contract of finalProject/Project/multi_frame_sr.cpp:122-210) ---------- */
@@ -439,6 +469,68 @@ int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw, int isRefe
 /* mfsr_burst_finish into out16Dev (device) followed by its D2H copy into out16Host on the same stream */
 int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights, uint16_t* out16Dev,
                            uint16_t* out16Host, mfsr_stream_t stream);
+/* ---- building blocks of stripe-sharded bursts (multi-GPU, include/mfsr_dist.h): a frame is ALIGNED on the rank that
+ * holds it (flow field + certainty mask into caller buffers, no accumulation), the ranks exchange the rows of raw / flow /
+ * mask their stripes need, and every rank FUSES all frames, in frame order, onto its own stripe of HR rows -- the
+ * summation order of the single-GPU burst, so the result is bit-identical to it. */
+/* flow field: float2 flowW x flowH (tracking resolution, raw-pixel units); certainty mask: float4 maskW x maskH */
+int mfsr_burst_field_dims(const mfsr_burst* b, int* flowW, int* flowH, int* maskW, int* maskH);
+/* stages A1, (I), B, D, F of mfsr_burst_add_frame without G; results copied to flowOut / maskOut (byte pitches) */
+int mfsr_burst_align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float2* flowOut, int flowPitch,
+                           mfsr_float4* maskOut, int maskPitch, mfsr_stream_t stream);
+/* stage G for 1 or 2 aligned frames on HR rows [rowBegin, rowEnd) (see mfsr_accumulateSuperResFullRows), with the kernel
+ * parameters of the burst's reference */
+int mfsr_burst_fuse_rows(mfsr_burst* b, int nFrames, const uint16_t* const* raws, const mfsr_float2* const* flows, int flowPitch,
+                         const mfsr_float4* const* masks, int maskPitch, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                         int accumulatorsUndefined, int rowBegin, int rowEnd, mfsr_stream_t stream);
+
+/* rows rank `rank` of `worldSize` owns and reads (host arithmetic only): HR rows [rowBegin, rowEnd) (multiples of 16), and
+ * of every frame's products the flow rows, certainty rows and raw rows its fuse can touch as long as the vertical flow
+ * stays within maxFlowY raw pixels (rawHalo - 3); mfsr_checkFlowBound verifies that on the device. */
+typedef struct {
+    int32_t rowBegin, rowEnd;
+    int32_t flowRow0, flowRows;
+    int32_t maskRow0, maskRows;
+    int32_t rawRow0, rawRows;
+    float maxFlowY;
+    int32_t reserved[3];
+} mfsr_stripe_plan;
+int mfsr_dist_stripe_plan(const mfsr_config* cfg, int worldSize, int rank, int rawHalo, mfsr_stripe_plan* out);
+/* *flag |= 1 (device int) if any |flow.y| of the `rows` flow rows starting at `flow` exceeds bound (NaN passes: it
+ * rounds to a zero shift) */
+int mfsr_checkFlowBound(const mfsr_float2* flow, int pitch, int width, int rows, float bound, int* flag, mfsr_stream_t stream);
+
+/* ---- frame streams (BASELINE configs[4]): a sliding window of 2*radius+1 frames around every
+ * frame, the reference's setTemporalAreaRadius(1) (finalProject/Project/multi_frame_sr.cpp:182).  Output t fuses frames
+ * [t-radius, t+radius] (clipped to the stream) with frame t as the reference -- exactly what one mfsr_burst_* burst per
+ * window gives -- but every frame is uploaded and PREPARED once (A1 half-resolution RGB, tracking pyramid, pre-alignment
+ * search pyramid), not once per window it takes part in.  cfg->frames is ignored.  framesInHostMemory: frames are
+ * (pinned) host pointers, uploaded on a copy stream the context owns, ahead of the compute. */
+typedef struct mfsr_stream mfsr_stream;
+size_t mfsr_stream_workspace_bytes(const mfsr_config* cfg, int radius);
+int mfsr_stream_create(mfsr_stream** out, const mfsr_config* cfg, int radius, int framesInHostMemory, void* workspace,
+                       size_t workspaceBytes);
+void mfsr_stream_destroy(mfsr_stream* s);
+/* hand over frame t = 0, 1, 2, ... (copied: the caller may reuse its buffer once the stream has passed the call).  From
+ * t = radius on each call also produces output t - radius into outImg (float3 HR, may be NULL) / out16 (u16 HR, may be
+ * NULL) and sets *produced to its index; before that *produced = -1. */
+int mfsr_stream_push(mfsr_stream* s, const uint16_t* frame, mfsr_float3* outImg, uint16_t* out16, long long* produced,
+                     mfsr_stream_t stream);
+/* end of the stream: each call produces the next outstanding output (windows clipped at the last frame); *produced = -1
+ * when none is left */
+int mfsr_stream_drain(mfsr_stream* s, mfsr_float3* outImg, uint16_t* out16, long long* produced, mfsr_stream_t stream);
+int mfsr_stream_reset(mfsr_stream* s);
+
+/* ---- whole burst with the JOINT SHIFT MINIMISER (stage C; ShiftMinimizerKernels.cu:81-258) in the loop.  Besides every
+ * (reference, k) pair the tracker measures every neighbouring pair (k, k+1); per tile the frame-to-frame shifts are the
+ * least-squares solution of all measurements with the worst outlier dropped until every residual is below 1 px^2, and
+ * the reference->k shifts (getOptimalShifts) replace the tracker's in the per-frame chain.  frames: cfg.frames device
+ * pointers; jointWorkspace: mfsr_burst_joint_workspace_bytes(cfg) device bytes; accumulators as for add_frame (a
+ * mfsr_burst_begin is issued inside); finish with mfsr_burst_finish.  Needs cfg.fused = 1, cfg.preAlign = 0. */
+size_t mfsr_burst_joint_workspace_bytes(const mfsr_config* cfg);
+int mfsr_burst_process_joint(mfsr_burst* b, const uint16_t* const* frames, void* jointWorkspace, size_t jointBytes,
+                             mfsr_float3* imgOut, mfsr_float3* totalWeights, mfsr_stream_t stream);
+
 /* HIP-event timing of the warp+fuse (accumulate) launches made by add_frame on
  * the caller's stream: timing(b,1) starts a series, timing_read synchronises with
  * the events and returns the summed kernel milliseconds, the launch count and the

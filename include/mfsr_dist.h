@@ -1,0 +1,70 @@
+/*
+ * mfsr_dist.h -- multi-GPU bursts: one process (or thread) per GPU of one node, RCCL over xGMI.
+ *
+ * The reference is single-GPU (cudaSetDevice(0), test_opencv/kernel.cu:45; no NCCL/MPI call site anywhere), so this
+ * boundary has no reference counterpart: it is the C-ABI of the frame-sharded burst that BASELINE.json's north_star
+ * asks for ("partition alignment+warp over the 8 GPUs of one node with an RCCL reduce onto rank 0's accumulation
+ * buffers over xGMI").  libmfsr_dist.so links librccl and libmfsr_hip.so; everything below is built on the burst
+ * building blocks of include/mfsr.h (mfsr_burst_align_frame / mfsr_burst_fuse_rows / mfsr_burst_finish_rows).
+ *
+ * Sharding: rank g ALIGNS frames {k : k mod world == g} (stages A1, I, B, D, F); the reference-frame products are
+ * LR-sized and are computed redundantly by every rank.  Three ways to combine:
+ *
+ *   MFSR_DIST_STRIPES (default)  fuse is sharded over HR row stripes: each rank sends every other rank the rows of
+ *       its frames' raw / flow / certainty that the peer's stripe reads (point-to-point ncclSend/ncclRecv, one per
+ *       xGMI link), then fuses ALL frames in frame order onto its own stripe, normalises it, and rank 0 collects the
+ *       u16 stripes.  Traffic per rank ~ N * LR * 38 B / world (0.13 GB at 4K x4, 16 frames, 8 GPUs) instead of the
+ *       2.8 GB of accumulators a reduce(-scatter) moves, and the summation order is the single-GPU one: the result is
+ *       BIT-IDENTICAL to the 1-GPU burst.
+ *   MFSR_DIST_REDUCE             every rank fuses its own frames onto private full-size accumulators, ncclReduce(sum)
+ *       of both onto rank 0, rank 0 finishes: north_star's literal wording.  Root-bound.
+ *   MFSR_DIST_REDUCE_SCATTER     as REDUCE with ncclReduceScatter over HR row stripes, stripe finish, u16 gather.
+ *   (REDUCE / REDUCE_SCATTER add the per-rank partial sums in another order than one GPU does: equal to fp32 rounding.)
+ *
+ * Conventions as in mfsr.h: int status (0 ok, >0 hipError_t, <0 MFSR_E_*; RCCL failures map to MFSR_E_COMM), nothing
+ * throws, all work is enqueued on the caller's stream, the caller owns every buffer.
+ */
+#ifndef MFSR_DIST_H
+#define MFSR_DIST_H
+
+#include "mfsr.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MFSR_DIST_STRIPES = 0, MFSR_DIST_REDUCE = 1, MFSR_DIST_REDUCE_SCATTER = 2 };
+#define MFSR_E_COMM (-5)        /* an RCCL call failed (logged to stderr) */
+#define MFSR_DIST_ID_BYTES 128  /* sizeof(ncclUniqueId) */
+#define MFSR_DIST_DEFAULT_RAW_HALO 64
+
+typedef struct mfsr_dist mfsr_dist;
+
+/* rank 0 creates the id (ncclGetUniqueId) and hands it to the other ranks by whatever means the launcher has */
+int mfsr_dist_get_unique_id(void* id);
+/* device bytes one rank needs for cfg (burst workspace, accumulators, per-frame products of all cfg->frames frames,
+ * u16 staging image) */
+size_t mfsr_dist_workspace_bytes(const mfsr_config* cfg, int worldSize);
+/* ncclCommInitRank on the CURRENT device + burst context.  cfg->frames = frames of the whole burst. */
+int mfsr_dist_create(mfsr_dist** out, const mfsr_config* cfg, int rank, int worldSize, const void* id, void* workspace,
+                     size_t workspaceBytes);
+void mfsr_dist_destroy(mfsr_dist* d);
+/* the burst context a mfsr_dist drives (for mfsr_burst_timing / mfsr_burst_debug_views); owned by d */
+mfsr_burst* mfsr_dist_burst(mfsr_dist* d);
+/* raw-row halo of the STRIPES exchange (default 64: vertical flow up to 61 raw pixels).  A halo >= the frame height
+ * exchanges whole raw frames: always valid, ~2.5x the traffic (still ~9x below summing accumulators) -- the fallback
+ * when mfsr_dist_process_burst reports status 1. */
+int mfsr_dist_set_raw_halo(mfsr_dist* d, int rawHalo);
+/* HR rows of `rank` in the STRIPES / REDUCE_SCATTER modes */
+int mfsr_dist_stripe(const mfsr_dist* d, int rank, int* rowBegin, int* rowEnd);
+/* One burst.  frames[k] = device pointer of frame k (dense u16) for the frames this rank owns (k mod world == rank) and
+ * for the reference frame on EVERY rank; other entries are ignored.  out16: dense interleaved u16 HR image, written on
+ * rank 0 only (may be NULL elsewhere).  status: device int, set to 0 / 1 on every rank: 1 = a frame's vertical flow
+ * exceeded the raw halo of the STRIPES exchange (result invalid: raise the halo or use another mode). */
+int mfsr_dist_process_burst(mfsr_dist* d, const uint16_t* const* frames, int mode, uint16_t* out16, int* status,
+                            mfsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFSR_DIST_H */

@@ -75,9 +75,10 @@ class Config(ctypes.Structure):
 _BY_VALUE = {
     "mfsr_float2": Float2, "mfsr_float3": Float3, "mfsr_float4": Float4, "mfsr_tex2d": Tex2D,
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
-    "mfsr_stream_t": ctypes.c_void_p,
+    "mfsr_stream_t": ctypes.c_void_p, "long long": ctypes.c_longlong,
 }
-_RET = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "void": None, "const char*": ctypes.c_char_p}
+_RET = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "void": None, "const char*": ctypes.c_char_p,
+        "mfsr_burst*": ctypes.c_void_p}
 
 
 def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[str, List[Tuple[str, str]]]]:
@@ -91,7 +92,7 @@ def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[str, List[Tuple[str
     text = re.sub(r"\{[^{}]*\}", " ", text)                    # struct / enum bodies
     protos = {}
     for stmt in text.split(";"):
-        m = re.match(r"^\s*((?:const\s+char\s*\*|int|size_t|void))\s+(mfsr_\w+)\s*\((.*)\)\s*$", stmt, flags=re.S)
+        m = re.match(r"^\s*((?:const\s+char\s*\*|mfsr_burst\s*\*|int|size_t|void))\s+(mfsr_\w+)\s*\((.*)\)\s*$", stmt, flags=re.S)
         if not m:
             continue
         ret = re.sub(r"\s+", " ", m.group(1)).replace(" *", "*").strip()
@@ -126,17 +127,32 @@ class MfsrError(RuntimeError):
         self.code = code
 
 
+class StripePlan(ctypes.Structure):
+    """mfsr_stripe_plan (include/mfsr.h)."""
+
+    _fields_ = [("rowBegin", ctypes.c_int32), ("rowEnd", ctypes.c_int32), ("flowRow0", ctypes.c_int32),
+                ("flowRows", ctypes.c_int32), ("maskRow0", ctypes.c_int32), ("maskRows", ctypes.c_int32),
+                ("rawRow0", ctypes.c_int32), ("rawRows", ctypes.c_int32), ("maxFlowY", ctypes.c_float),
+                ("reserved", ctypes.c_int32 * 3)]
+
+
+DIST_HEADER_PATH = os.path.join(_ROOT, "include", "mfsr_dist.h")
+DIST_LIB_PATH = os.path.join(_PKG_DIR, "lib", "libmfsr_dist.so")
+DIST_STRIPES, DIST_REDUCE, DIST_REDUCE_SCATTER = 0, 1, 2
+DIST_ID_BYTES = 128
+
+
 class _Lib:
     """Loaded C-ABI; attribute access returns checked wrappers (raise on rc != 0)."""
 
-    def __init__(self, path: str = LIB_PATH):
+    def __init__(self, path: str = LIB_PATH, header: str = HEADER_PATH, mode: int = ctypes.DEFAULT_MODE):
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
         self.path = path
-        self.cdll = ctypes.CDLL(path)
-        self.protos = parse_header()
+        self.cdll = ctypes.CDLL(path, mode=mode)
+        self.protos = parse_header(header)
         self.raw = {}
         for name, (ret, args) in self.protos.items():
             fn = getattr(self.cdll, name)  # AttributeError if the library lacks a declared symbol
@@ -156,7 +172,8 @@ class _Lib:
         def checked(*a):
             rc = raw(*a)
             if rc != 0:
-                msg = self.raw["mfsr_error_string"](rc)
+                es = self.raw.get("mfsr_error_string") or lib().raw["mfsr_error_string"]
+                msg = es(rc)
                 raise MfsrError(full, rc, msg.decode() if msg else "?")
             return rc
 
@@ -165,6 +182,7 @@ class _Lib:
 
 
 _lib = None
+_dist_lib = None
 
 
 def lib() -> _Lib:
@@ -172,6 +190,15 @@ def lib() -> _Lib:
     if _lib is None:
         _lib = _Lib()
     return _lib
+
+
+def dist_lib() -> _Lib:
+    """libmfsr_dist.so (include/mfsr_dist.h): the multi-GPU layer, RCCL + libmfsr_hip.so."""
+    global _dist_lib
+    if _dist_lib is None:
+        lib()   # libmfsr_hip.so first, so that both bind to the one copy of its process-wide state
+        _dist_lib = _Lib(DIST_LIB_PATH, DIST_HEADER_PATH)
+    return _dist_lib
 
 
 def f3(v) -> Float3:

@@ -82,13 +82,13 @@ template <int GEOM, bool FAST>
 __global__ void __launch_bounds__(256)
     k_accumulateSuperRes(const uint16_t* __restrict__ dataIn, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
                          const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 lv,
-                         int dimX, int dimY, int scale, int strideOut, int strideMask, int cfa)
+                         int dimX, int dimY, int scale, int strideOut, int strideMask, int cfa, int rowBegin, int rowEnd)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y + rowBegin;  // [rowBegin, rowEnd): output row window of the launch
     const int outW = (GEOM == GEOM_CROP) ? dimX : dimX * scale;
     const int outH = (GEOM == GEOM_CROP) ? dimY : dimY * scale;
-    if (x < 1 || y < 1 || x >= outW - 1 || y >= outH - 1) return;
+    if (x < 1 || y < 1 || x >= outW - 1 || y >= outH - 1 || y >= rowEnd) return;
     accumulate_pixel_generic<GEOM, FAST>(x, y, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, lv, dimX,
                                          dimY, scale, strideOut, strideMask, cfa);
 }
@@ -107,13 +107,13 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
                                        mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
                                        mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
                                        mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
-                                       int fresh, mfsr_stream_t stream);  // accumulate_fast.hip
+                                       int fresh, int rowBegin, int rowEnd, mfsr_stream_t stream);  // accumulate_fast.hip
 
 int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
                                       mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
                                       mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
                                       mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
-                                      int fresh, mfsr_stream_t stream);  // accumulate_fast.hip
+                                      int fresh, int rowBegin, int rowEnd, mfsr_stream_t stream);  // accumulate_fast.hip
 
 static int check_superres_args(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
                                const mfsr_float4* certaintyMask, const mfsr_tex2d& kernelParam, const mfsr_tex2d& shifts,
@@ -142,18 +142,19 @@ extern "C" int mfsr_accumulateImagesSuperRes(const uint16_t* dataIn, mfsr_float3
     if (g_accumulate_fast)
         hipLaunchKernelGGL((k_accumulateSuperRes<GEOM_CROP, true>), grid, block, 0, mfsr_s(stream), dataIn, (pix3*)imgOut,
                            (pix3*)totalWeights, (const float4*)certaintyMask, kernelParam, shifts, lv, dimX, dimY, 2,
-                           strideOut, strideMask, mfsr_cfa_packed());
+                           strideOut, strideMask, mfsr_cfa_packed(), 0, dimY);
     else
         hipLaunchKernelGGL((k_accumulateSuperRes<GEOM_CROP, false>), grid, block, 0, mfsr_s(stream), dataIn,
                            (pix3*)imgOut, (pix3*)totalWeights, (const float4*)certaintyMask, kernelParam, shifts, lv, dimX,
-                           dimY, 2, strideOut, strideMask, mfsr_cfa_packed());
+                           dimY, 2, strideOut, strideMask, mfsr_cfa_packed(), 0, dimY);
     return mfsr_launch_status("accumulateImagesSuperRes");
 }
 
-extern "C" int mfsr_accumulateSuperResFull(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
-                                           const mfsr_float4* certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts,
-                                           mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int scale,
-                                           int strideOut, int strideMask, mfsr_stream_t stream)
+// one frame, HR row window [rowBegin, rowEnd) (whole frame: 0, scale*dimY)
+static int accumulate_full_rows(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                                const mfsr_float4* certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts,
+                                mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int scale, int strideOut,
+                                int strideMask, int rowBegin, int rowEnd, mfsr_stream_t stream)
 {
     MFSR_REQUIRE(scale >= 1 && scale <= 8);
     int rc = check_superres_args(dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, dimX, dimY,
@@ -161,23 +162,32 @@ extern "C" int mfsr_accumulateSuperResFull(const uint16_t* dataIn, mfsr_float3* 
     if (rc) return rc;
     if (g_accumulate_fast == 2 && scale == 2 &&
         mfsr_try_launch_accumulate2x_strip(1, &dataIn, imgOut, totalWeights, &certaintyMask, kernelParam, &shifts, whiteLevel,
-                                           blackLevel, dimX, dimY, strideOut, strideMask, 0, stream) == 1)
+                                           blackLevel, dimX, dimY, strideOut, strideMask, 0, rowBegin, rowEnd, stream) == 1)
         return mfsr_launch_status("accumulateSuperResFull(strip)");
     if (g_accumulate_fast == 2 && scale == 4 &&
         mfsr_try_launch_accumulate4x_tile(1, &dataIn, imgOut, totalWeights, &certaintyMask, kernelParam, &shifts, whiteLevel,
-                                          blackLevel, dimX, dimY, strideOut, strideMask, 0, stream) == 1)
+                                          blackLevel, dimX, dimY, strideOut, strideMask, 0, rowBegin, rowEnd, stream) == 1)
         return mfsr_launch_status("accumulateSuperResFull(x4 tile)");
-    dim3 block(64, 4), grid(mfsr_cdiv((long long)dimX * scale, 64), mfsr_cdiv((long long)dimY * scale, 4));
+    dim3 block(64, 4), grid(mfsr_cdiv((long long)dimX * scale, 64), mfsr_cdiv(rowEnd - rowBegin, 4));
     const Levels3 lv = make_levels(whiteLevel, blackLevel);
     if (g_accumulate_fast)
         hipLaunchKernelGGL((k_accumulateSuperRes<GEOM_FULL, true>), grid, block, 0, mfsr_s(stream), dataIn, (pix3*)imgOut,
                            (pix3*)totalWeights, (const float4*)certaintyMask, kernelParam, shifts, lv, dimX, dimY, scale,
-                           strideOut, strideMask, mfsr_cfa_packed());
+                           strideOut, strideMask, mfsr_cfa_packed(), rowBegin, rowEnd);
     else
         hipLaunchKernelGGL((k_accumulateSuperRes<GEOM_FULL, false>), grid, block, 0, mfsr_s(stream), dataIn,
                            (pix3*)imgOut, (pix3*)totalWeights, (const float4*)certaintyMask, kernelParam, shifts, lv, dimX,
-                           dimY, scale, strideOut, strideMask, mfsr_cfa_packed());
+                           dimY, scale, strideOut, strideMask, mfsr_cfa_packed(), rowBegin, rowEnd);
     return mfsr_launch_status("accumulateSuperResFull");
+}
+
+extern "C" int mfsr_accumulateSuperResFull(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                                           const mfsr_float4* certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts,
+                                           mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int scale,
+                                           int strideOut, int strideMask, mfsr_stream_t stream)
+{
+    return accumulate_full_rows(dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, whiteLevel, blackLevel, dimX, dimY,
+                                scale, strideOut, strideMask, 0, scale * dimY, stream);
 }
 
 extern "C" int mfsr_accumulateSuperResFullN(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
@@ -214,14 +224,19 @@ extern "C" int mfsr_accumulateSuperResFull2(const uint16_t* dataIn0, const uint1
 // nFrames (1 or 2) frames in one call; accumulatorsUndefined != 0: the planes are overwritten as if
 // they had been zeroed before the call (the first launch of a burst: saves the memset and the read of
 // both planes -- 0 + x == x, so the result equals the zeroed-and-accumulated one bit for bit).
-extern "C" int mfsr_accumulateSuperResFullN(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
-                                            mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
-                                            mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
-                                            mfsr_float3 blackLevel, int dimX, int dimY, int scale, int strideOut,
-                                            int strideMask, int accumulatorsUndefined, mfsr_stream_t stream)
+// Only HR rows [rowBegin, rowEnd) are touched (stripe-sharded bursts): rowBegin a multiple of 16, rowEnd a multiple
+// of 16 or the frame's last row + 1; every pixel of the window gets exactly what the whole-frame call gives it.
+extern "C" int mfsr_accumulateSuperResFullRows(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
+                                               mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
+                                               mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
+                                               mfsr_float3 blackLevel, int dimX, int dimY, int scale, int strideOut,
+                                               int strideMask, int accumulatorsUndefined, int rowBegin, int rowEnd,
+                                               mfsr_stream_t stream)
 {
     MFSR_REQUIRE(nFrames >= 1 && nFrames <= 2 && dataIn && certaintyMask && shifts);
     MFSR_REQUIRE(scale >= 1 && scale <= 8);
+    const int hrH = scale * dimY;
+    MFSR_REQUIRE(rowBegin >= 0 && rowBegin < rowEnd && rowEnd <= hrH && (rowBegin % 16) == 0 && ((rowEnd % 16) == 0 || rowEnd == hrH));
     for (int n = 0; n < nFrames; n++) {
         const int rc = check_superres_args(dataIn[n], imgOut, totalWeights, certaintyMask[n], kernelParam, shifts[n], dimX, dimY,
                                            dimX * scale, strideOut, strideMask);
@@ -230,26 +245,39 @@ extern "C" int mfsr_accumulateSuperResFullN(int nFrames, const uint16_t* const* 
     const int fresh = accumulatorsUndefined ? 1 : 0;
     if (g_accumulate_fast == 2 && scale == 2) {
         const int r = mfsr_try_launch_accumulate2x_strip(nFrames, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts,
-                                                         whiteLevel, blackLevel, dimX, dimY, strideOut, strideMask, fresh, stream);
+                                                         whiteLevel, blackLevel, dimX, dimY, strideOut, strideMask, fresh, rowBegin,
+                                                         rowEnd, stream);
         if (r == 1) return mfsr_launch_status("accumulateSuperResFullN(strip)");
         if (r < 0) return MFSR_E_INVALID;
     }
     if (g_accumulate_fast == 2 && scale == 4) {
         const int r = mfsr_try_launch_accumulate4x_tile(nFrames, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts,
-                                                        whiteLevel, blackLevel, dimX, dimY, strideOut, strideMask, fresh, stream);
+                                                        whiteLevel, blackLevel, dimX, dimY, strideOut, strideMask, fresh, rowBegin,
+                                                        rowEnd, stream);
         if (r == 1) return mfsr_launch_status("accumulateSuperResFullN(x4 tile)");
         if (r < 0) return MFSR_E_INVALID;
     }
     if (fresh) {
-        const size_t bytes = (size_t)dimY * scale * strideOut;
-        MFSR_HIP_TRY(hipMemsetAsync(imgOut, 0, bytes, mfsr_s(stream)));
-        MFSR_HIP_TRY(hipMemsetAsync(totalWeights, 0, bytes, mfsr_s(stream)));
+        const size_t off = (size_t)rowBegin * strideOut, bytes = (size_t)(rowEnd - rowBegin) * strideOut;
+        MFSR_HIP_TRY(hipMemsetAsync((char*)imgOut + off, 0, bytes, mfsr_s(stream)));
+        MFSR_HIP_TRY(hipMemsetAsync((char*)totalWeights + off, 0, bytes, mfsr_s(stream)));
     }
     for (int n = 0; n < nFrames; n++) {
-        const int rc = mfsr_accumulateSuperResFull(dataIn[n], imgOut, totalWeights, certaintyMask[n], kernelParam, shifts[n],
-                                                   whiteLevel, blackLevel, dimX, dimY, scale, strideOut, strideMask, stream);
+        const int rc = accumulate_full_rows(dataIn[n], imgOut, totalWeights, certaintyMask[n], kernelParam, shifts[n], whiteLevel,
+                                            blackLevel, dimX, dimY, scale, strideOut, strideMask, rowBegin, rowEnd, stream);
         if (rc) return rc;
     }
     return MFSR_OK;
 }
 
+extern "C" int mfsr_accumulateSuperResFullN(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
+                                            mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
+                                            mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
+                                            mfsr_float3 blackLevel, int dimX, int dimY, int scale, int strideOut,
+                                            int strideMask, int accumulatorsUndefined, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(scale >= 1 && scale <= 8 && dimY > 0);
+    return mfsr_accumulateSuperResFullRows(nFrames, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, whiteLevel,
+                                           blackLevel, dimX, dimY, scale, strideOut, strideMask, accumulatorsUndefined, 0,
+                                           scale * dimY, stream);
+}

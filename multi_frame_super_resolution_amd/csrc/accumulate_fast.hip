@@ -305,7 +305,7 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
 __global__ void __launch_bounds__(256)
     k_accumulateMargin(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
                        const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
-                       int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int scale)
+                       int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int scale, int rowBegin, int rowEnd)
 {
     const int hrW = scale * dimX, hrH = scale * dimY, M = STRIP_MARGIN;
     const int rowLen = hrW - 2;                    // x in [1, hrW-1)
@@ -330,6 +330,7 @@ __global__ void __launch_bounds__(256)
     } else {
         return;
     }
+    if (y < rowBegin || y >= rowEnd) return;  // HR row window of this launch (stripe-sharded bursts)
     accumulate_pixel_generic<GEOM_FULL, true>(x, y, raw, imgOut, totalWeights, certaintyMask, kernelParam, shifts, glv, dimX,
                                               dimY, scale, strideOut, strideMask, cfaPacked);
 }
@@ -477,10 +478,10 @@ __device__ __forceinline__ void strip_frame(int tx, int Y, int X0, const uint16_
 template <int CFA, int FR, int NF>
 __global__ void __launch_bounds__(256)
     k_accumulate2xStrip(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
-                        Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
+                        Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int rowBlock0)
 {
     const int tx = blockIdx.x * 64 + threadIdx.x;
-    const int Y = blockIdx.y * 4 + threadIdx.y;
+    const int Y = (blockIdx.y + rowBlock0) * 4 + threadIdx.y;
     const int hrW = 2 * dimX, hrH = 2 * dimY;
     const int X0 = 4 * tx;
     if (X0 < STRIP_MARGIN || X0 >= hrW - STRIP_MARGIN || Y < STRIP_MARGIN || Y >= hrH - STRIP_MARGIN) return;
@@ -539,7 +540,7 @@ template <int CFA, int NF>
 __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     k_accumulate2xTile(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
                        Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked,
-                       int tilesX, int tilesY, int tilesPerXcd, int fresh)
+                       int tilesX, int tilesY, int tilesPerXcd, int fresh, int tileY0)
 {
     // Optional XCD-aware tile order (tilesPerXcd > 0).  Workgroups are dealt round-robin to the 8 XCDs
     // (workgroup i -> XCD i & 7), each with its own L2; vertically adjacent tiles share a field-texel
@@ -550,7 +551,8 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     const int pid = (int)blockIdx.x;
     const int tile = tilesPerXcd > 0 ? (pid & 7) * tilesPerXcd + (pid >> 3) : pid;  // tilesPerXcd == 0: launch order (A/B)
     if (tile >= tilesX * tilesY) return;  // whole workgroup (uniform), before any barrier
-    const int bIdY = tile / tilesX, bIdX = tile - bIdY * tilesX;
+    const int bIdYrel = tile / tilesX, bIdX = tile - bIdYrel * tilesX;
+    const int bIdY = bIdYrel + tileY0;  // tileY0: first tile row of this launch's HR row window
     __shared__ float4 sK[3][TILE_COLS];  // .w = 1 if the texel is PSD and finite, else 0
     __shared__ float2 sF[NF][3][TILE_COLS];
     __shared__ float4 sM[NF][3][TILE_COLS];
@@ -870,9 +872,10 @@ template <int CFA, int NF>
 __global__ void __launch_bounds__(256, 3)
     k_accumulate4xTile(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
                        Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked,
-                       int tilesX, int fresh)
+                       int tilesX, int fresh, int tileY0)
 {
-    const int bIdY = (int)blockIdx.x / tilesX, bIdX = (int)blockIdx.x - bIdY * tilesX;
+    const int bIdYrel = (int)blockIdx.x / tilesX, bIdX = (int)blockIdx.x - bIdYrel * tilesX;
+    const int bIdY = bIdYrel + tileY0;  // tileY0: first tile row of this launch's HR row window
     const int hrW = 4 * dimX, hrH = 4 * dimY;
     const int Y0 = 2 * bIdY;
     if (Y0 < STRIP_MARGIN || Y0 >= hrH - STRIP_MARGIN) return;  // whole workgroup (margin rows)
@@ -1096,30 +1099,46 @@ bool tile_kernel_ok(mfsr_tex2d kp, mfsr_tex2d sh, int dimX, int dimY)
 
 template <int CFA, int NF>
 void launch_tile(dim3 grid, dim3 block, hipStream_t st, const TileFrames<NF>& fr, pix3* imgOut, pix3* tw, mfsr_tex2d kp,
-                 Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int fresh)
+                 Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int fresh, int tileY0)
 {
     const int tilesX = (int)grid.x, tilesY = (int)grid.y;
     const int tilesPerXcd = g_strip_xcd_remap ? mfsr_cdiv(tilesX * tilesY, 8) : 0;
     hipLaunchKernelGGL((k_accumulate2xTile<CFA, NF>), dim3(tilesPerXcd ? 8 * tilesPerXcd : tilesX * tilesY), block, 0, st, fr,
-                       imgOut, tw, kp, glv, lv, dimX, dimY, strideOut, strideMask, cfaPacked, tilesX, tilesY, tilesPerXcd, fresh);
+                       imgOut, tw, kp, glv, lv, dimX, dimY, strideOut, strideMask, cfaPacked, tilesX, tilesY, tilesPerXcd, fresh, tileY0);
 }
 
 template <int CFA, int NF>
 void launch_strip_regs(dim3 grid, dim3 block, hipStream_t st, const TileFrames<NF>& fr, pix3* imgOut, pix3* tw, mfsr_tex2d kp,
-                       Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked)
+                       Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int rowBlock0)
 {
     const int hrW = 2 * dimX, hrH = 2 * dimY;
     bool same = true;
     for (int n = 0; n < NF; n++) same = same && kp.width == fr.f[n].shifts.width && kp.height == fr.f[n].shifts.height;
     if (same && kp.width * 4 == hrW && kp.height * 4 == hrH && kp.width >= 4)
         hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 4, NF>), grid, block, 0, st, fr, imgOut, tw, kp, glv, lv, dimX, dimY,
-                           strideOut, strideMask, cfaPacked);
+                           strideOut, strideMask, cfaPacked, rowBlock0);
     else if (same && kp.width * 2 == hrW && kp.height * 2 == hrH && kp.width >= 4)
         hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 2, NF>), grid, block, 0, st, fr, imgOut, tw, kp, glv, lv, dimX, dimY,
-                           strideOut, strideMask, cfaPacked);
+                           strideOut, strideMask, cfaPacked, rowBlock0);
     else
         hipLaunchKernelGGL((k_accumulate2xStrip<CFA, 0, NF>), grid, block, 0, st, fr, imgOut, tw, kp, glv, lv, dimX, dimY,
-                           strideOut, strideMask, cfaPacked);
+                           strideOut, strideMask, cfaPacked, rowBlock0);
+}
+
+// fresh accumulators: the tile kernels write every row of their window outside the top and bottom margin bands
+// (rows [0, M) and [hrH - M, hrH)); zero the part of those bands that lies inside the window
+int zero_margin_bands(mfsr_float3* imgOut, mfsr_float3* totalWeights, int hrH, int strideOut, int rowBegin, int rowEnd, hipStream_t st)
+{
+    const int bands[2][2] = {{0, STRIP_MARGIN}, {hrH - STRIP_MARGIN, hrH}};
+    for (int i = 0; i < 2; i++) {
+        const int r0 = bands[i][0] > rowBegin ? bands[i][0] : rowBegin, r1 = bands[i][1] < rowEnd ? bands[i][1] : rowEnd;
+        if (r1 <= r0) continue;
+        for (int p2 = 0; p2 < 2; p2++) {
+            char* base = p2 ? (char*)totalWeights : (char*)imgOut;
+            if (hipMemsetAsync(base + (size_t)r0 * strideOut, 0, (size_t)(r1 - r0) * strideOut, st) != hipSuccess) return -1;
+        }
+    }
+    return 0;
 }
 
 void read_env_once()
@@ -1145,7 +1164,7 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
                                        mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
                                        mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
                                        mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
-                                       int fresh, mfsr_stream_t stream)
+                                       int fresh, int rowBegin, int rowEnd, mfsr_stream_t stream)
 {
     read_env_once();
     if (nFrames < 1 || nFrames > 2) return 0;
@@ -1167,7 +1186,9 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
         lv.invWhite[c] = 1.0f / wl[c];
     }
     const int hrW = 2 * dimX, hrH = 2 * dimY;
-    dim3 block(64, 4), grid(mfsr_cdiv(hrW / 4, 64), mfsr_cdiv(hrH, 4));
+    // HR row window [rowBegin, rowEnd): whole 4-row tile rows (the caller aligns it to 16 rows or the frame's end)
+    const int rowBlock0 = rowBegin / 4, rowBlocks = mfsr_cdiv(rowEnd, 4) - rowBlock0;
+    dim3 block(64, 4), grid(mfsr_cdiv(hrW / 4, 64), rowBlocks);
     hipStream_t st = mfsr_s(stream);
     pix3* pI = (pix3*)imgOut;
     pix3* pT = (pix3*)totalWeights;
@@ -1181,22 +1202,19 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
     if (fresh) {
         if (tileFirst) {
             tileFresh = 1;
-            const size_t band = (size_t)STRIP_MARGIN * strideOut;
-            for (int p2 = 0; p2 < 2; p2++) {
-                char* base = p2 ? (char*)totalWeights : (char*)imgOut;
-                if (hipMemsetAsync(base, 0, band, st) != hipSuccess) return -1;
-                if (hipMemsetAsync(base + (size_t)(hrH - STRIP_MARGIN) * strideOut, 0, band, st) != hipSuccess) return -1;
-            }
+            if (zero_margin_bands(imgOut, totalWeights, hrH, strideOut, rowBegin, rowEnd, st) != 0) return -1;
         } else {
-            if (hipMemsetAsync(imgOut, 0, (size_t)hrH * strideOut, st) != hipSuccess) return -1;
-            if (hipMemsetAsync(totalWeights, 0, (size_t)hrH * strideOut, st) != hipSuccess) return -1;
+            const size_t off = (size_t)rowBegin * strideOut, bytes = (size_t)(rowEnd - rowBegin) * strideOut;
+            if (hipMemsetAsync((char*)imgOut + off, 0, bytes, st) != hipSuccess) return -1;
+            if (hipMemsetAsync((char*)totalWeights + off, 0, bytes, st) != hipSuccess) return -1;
         }
     }
     auto launch_margin = [&](int n) {
         const int M = STRIP_MARGIN;
         const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
         hipLaunchKernelGGL(k_accumulateMargin, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, st, dataIn[n], pI, pT,
-                           (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp, 2);
+                           (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp, 2,
+                           rowBegin, rowEnd);
     };
 #define STRIP_CASE(a, b, c, d)                                                                                         \
     case pack_cfa(a, b, c, d):                                                                                         \
@@ -1208,7 +1226,7 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
                 fr.f[n].shifts = shifts[n];                                                                            \
             }                                                                                                          \
             launch_tile<pack_cfa(a, b, c, d), 2>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY, strideOut, \
-                                                 strideMask, cp, tileFresh);                                           \
+                                                 strideMask, cp, tileFresh, rowBlock0);                                           \
             launch_margin(0);                                                                                          \
             launch_margin(1);                                                                                          \
         } else if (nFrames == 2) {                                                                                     \
@@ -1219,7 +1237,7 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
                 fr.f[n].shifts = shifts[n];                                                                            \
             }                                                                                                          \
             launch_strip_regs<pack_cfa(a, b, c, d), 2>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY,  \
-                                                       strideOut, strideMask, cp);                                     \
+                                                       strideOut, strideMask, cp, rowBlock0);                                    \
             launch_margin(0);                                                                                          \
             launch_margin(1);                                                                                          \
         } else {                                                                                                       \
@@ -1229,10 +1247,10 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
             fr.f[0].shifts = shifts[0];                                                                                \
             if (tile_kernel_ok(kernelParam, shifts[0], dimX, dimY))                                                    \
                 launch_tile<pack_cfa(a, b, c, d), 1>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY,    \
-                                                     strideOut, strideMask, cp, tileFresh);                            \
+                                                     strideOut, strideMask, cp, tileFresh, rowBlock0);                           \
             else                                                                                                       \
                 launch_strip_regs<pack_cfa(a, b, c, d), 1>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX,    \
-                                                           dimY, strideOut, strideMask, cp);                           \
+                                                           dimY, strideOut, strideMask, cp, rowBlock0);                           \
             launch_margin(0);                                                                                          \
         }                                                                                                              \
         return 1;
@@ -1254,7 +1272,7 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
                                       mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
                                       mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
                                       mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
-                                      int fresh, mfsr_stream_t stream)
+                                      int fresh, int rowBegin, int rowEnd, mfsr_stream_t stream)
 {
     read_env_once();
     if (nFrames < 1 || nFrames > 2 || !g_strip_use_tile) return 0;
@@ -1283,21 +1301,19 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
     pix3* pI = (pix3*)imgOut;
     pix3* pT = (pix3*)totalWeights;
     const int cp = mfsr_cfa_packed();
-    const int tilesX = mfsr_cdiv(hrW, 512), tilesY = hrH / 2;
+    // HR row window [rowBegin, rowEnd): whole 2-row tile rows
+    const int tileY0 = rowBegin / 2;
+    const int tilesX = mfsr_cdiv(hrW, 512), tilesY = mfsr_cdiv(rowEnd, 2) - tileY0;
     const dim3 block(64, 4), grid(tilesX * tilesY);
     if (fresh) {  // the top and bottom margin bands are the only rows the tile kernel does not write
-        const size_t band = (size_t)STRIP_MARGIN * strideOut;
-        for (int p2 = 0; p2 < 2; p2++) {
-            char* base = p2 ? (char*)totalWeights : (char*)imgOut;
-            if (hipMemsetAsync(base, 0, band, st) != hipSuccess) return -1;
-            if (hipMemsetAsync(base + (size_t)(hrH - STRIP_MARGIN) * strideOut, 0, band, st) != hipSuccess) return -1;
-        }
+        if (zero_margin_bands(imgOut, totalWeights, hrH, strideOut, rowBegin, rowEnd, st) != 0) return -1;
     }
     auto launch_margin = [&](int n) {
         const int M = STRIP_MARGIN;
         const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
         hipLaunchKernelGGL(k_accumulateMargin, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, st, dataIn[n], pI, pT,
-                           (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp, 4);
+                           (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp, 4,
+                           rowBegin, rowEnd);
     };
 #define X4_CASE(a, b, c, d)                                                                                            \
     case pack_cfa(a, b, c, d):                                                                                         \
@@ -1309,7 +1325,7 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
                 fr.f[n].shifts = shifts[n];                                                                            \
             }                                                                                                          \
             hipLaunchKernelGGL((k_accumulate4xTile<pack_cfa(a, b, c, d), 2>), grid, block, 0, st, fr, pI, pT, kernelParam, \
-                               glv, lv, dimX, dimY, strideOut, strideMask, cp, tilesX, fresh ? 1 : 0);                 \
+                               glv, lv, dimX, dimY, strideOut, strideMask, cp, tilesX, fresh ? 1 : 0, tileY0);                 \
             launch_margin(0);                                                                                          \
             launch_margin(1);                                                                                          \
         } else {                                                                                                       \
@@ -1318,7 +1334,7 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
             fr.f[0].mask = (const float4*)certaintyMask[0];                                                            \
             fr.f[0].shifts = shifts[0];                                                                                \
             hipLaunchKernelGGL((k_accumulate4xTile<pack_cfa(a, b, c, d), 1>), grid, block, 0, st, fr, pI, pT, kernelParam, \
-                               glv, lv, dimX, dimY, strideOut, strideMask, cp, tilesX, fresh ? 1 : 0);                 \
+                               glv, lv, dimX, dimY, strideOut, strideMask, cp, tilesX, fresh ? 1 : 0, tileY0);                 \
             launch_margin(0);                                                                                          \
         }                                                                                                              \
         return 1;

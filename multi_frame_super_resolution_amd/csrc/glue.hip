@@ -17,6 +17,7 @@ extern "C" const char* mfsr_error_string(int code)
         case MFSR_E_UNSUPPORTED: return "unsupported parameter";
         case MFSR_E_NODEVICE: return "no HIP device";
         case MFSR_E_WORKSPACE: return "workspace too small";
+        case -5: return "RCCL call failed (mfsr_dist)";  // MFSR_E_COMM, include/mfsr_dist.h
         default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
@@ -513,7 +514,7 @@ __global__ void __launch_bounds__(256)
     k_finishFused(const pix3* __restrict__ finalImg, const pix3* __restrict__ weight, int imgPitch,
                   const pix3* __restrict__ fallback, int fbPitch, int fbW, int fbH, float u0, float u1, float v0, float v1,
                   pix3* __restrict__ outImg, int outPitch, uint16_t* __restrict__ out16, int width, int height,
-                  float threshold, int applyGamma, float maxOut)
+                  float threshold, int applyGamma, float maxOut, int rowOffset, int fullHeight)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -523,7 +524,9 @@ __global__ void __launch_bounds__(256)
     pix3 inout = {0.0f, 0.0f, 0.0f};
     if (fallback) {
         const float u = u0 + (u1 - u0) * (((float)x + 0.5f) / (float)width);
-        const float v = v0 + (v1 - v0) * (((float)y + 0.5f) / (float)height);
+        // row y of this launch is row y + rowOffset of a fullHeight-row image: the same float expression as the whole-image
+        // launch evaluates for that row, so a stripe-wise finish is bit-identical to the whole one
+        const float v = v0 + (v1 - v0) * (((float)(y + rowOffset) + 0.5f) / (float)fullHeight);
         inout = sample_pix3(fallback, fbPitch, fbW, fbH, u, v);
     }
     inout.x = apply_weight_f(inout.x, val.x, w.x, threshold);
@@ -543,19 +546,56 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-extern "C" int mfsr_finishFused(const mfsr_float3* finalImg, const mfsr_float3* weight, int imgPitch,
-                                const mfsr_float3* fallback, int fbPitch, int fbW, int fbH, float u0, float u1, float v0,
-                                float v1, mfsr_float3* outImg, int outPitch, uint16_t* out16, int width, int height,
-                                float threshold, int applyGamma, float maxOut, mfsr_stream_t stream)
+// rows [rowOffset, rowOffset + height) of a fullHeight-row image whose fallback window is (u0..u1, v0..v1); the image
+// pointers are those of the first row of the stripe
+extern "C" int mfsr_finishFusedRows(const mfsr_float3* finalImg, const mfsr_float3* weight, int imgPitch,
+                                    const mfsr_float3* fallback, int fbPitch, int fbW, int fbH, float u0, float u1, float v0,
+                                    float v1, mfsr_float3* outImg, int outPitch, uint16_t* out16, int width, int height,
+                                    float threshold, int applyGamma, float maxOut, int rowOffset, int fullHeight,
+                                    mfsr_stream_t stream)
 {
     MFSR_REQUIRE(finalImg && weight && (outImg || out16) && width > 0 && height > 0);
     MFSR_REQUIRE((long long)imgPitch >= 12LL * width && (imgPitch & 3) == 0);
     if (outImg) MFSR_REQUIRE((long long)outPitch >= 12LL * width && (outPitch & 3) == 0);
     if (fallback) MFSR_REQUIRE(fbW > 0 && fbH > 0 && (long long)fbPitch >= 12LL * fbW && (fbPitch & 3) == 0);
     MFSR_REQUIRE(maxOut > 0 && maxOut <= 65535.0f);
+    MFSR_REQUIRE(rowOffset >= 0 && fullHeight >= rowOffset + height);
     dim3 block(64, 4), grid(mfsr_cdiv(width, 64), mfsr_cdiv(height, 4));
     hipLaunchKernelGGL(k_finishFused, grid, block, 0, mfsr_s(stream), (const pix3*)finalImg, (const pix3*)weight, imgPitch,
                        (const pix3*)fallback, fbPitch, fbW, fbH, u0, u1, v0, v1, (pix3*)outImg, outPitch, out16, width,
-                       height, threshold, applyGamma, maxOut);
+                       height, threshold, applyGamma, maxOut, rowOffset, fullHeight);
     return mfsr_launch_status("finishFused");
+}
+
+extern "C" int mfsr_finishFused(const mfsr_float3* finalImg, const mfsr_float3* weight, int imgPitch,
+                                const mfsr_float3* fallback, int fbPitch, int fbW, int fbH, float u0, float u1, float v0,
+                                float v1, mfsr_float3* outImg, int outPitch, uint16_t* out16, int width, int height,
+                                float threshold, int applyGamma, float maxOut, mfsr_stream_t stream)
+{
+    return mfsr_finishFusedRows(finalImg, weight, imgPitch, fallback, fbPitch, fbW, fbH, u0, u1, v0, v1, outImg, outPitch, out16,
+                                width, height, threshold, applyGamma, maxOut, 0, height, stream);
+}
+
+
+// ---- stripe-sharded bursts: is the vertical flow of these rows within the raw halo that was exchanged? ----------------
+__global__ void __launch_bounds__(256) k_checkFlowBound(const float2* __restrict__ flow, int pitch, int width, int rows, float bound,
+                                                       int* __restrict__ flag)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    bool bad = false;
+    if (x < width && y < rows) {
+        const float v = row_ptr(flow, pitch, y)[x].y;
+        bad = fabsf(v) > bound;  // NaN rounds to a zero shift in the fuse kernels (v_cvt_i32_f32): harmless
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+extern "C" int mfsr_checkFlowBound(const mfsr_float2* flow, int pitch, int width, int rows, float bound, int* flag,
+                                   mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(flow && flag && width > 0 && rows > 0 && (long long)pitch >= 8LL * width && (pitch & 7) == 0);
+    dim3 block(64, 4), grid(mfsr_cdiv(width, 64), mfsr_cdiv(rows, 4));
+    hipLaunchKernelGGL(k_checkFlowBound, grid, block, 0, mfsr_s(stream), (const float2*)flow, pitch, width, rows, bound, flag);
+    return mfsr_launch_status("checkFlowBound");
 }

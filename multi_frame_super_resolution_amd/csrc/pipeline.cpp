@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "common.hpp"
 
@@ -266,6 +267,12 @@ struct mfsr_burst {
     int upCounter, refCounter;
     const uint16_t* refHost;                // host pointer of the current reference and its device copy
     const uint16_t* refDev;
+    // mfsr_stream: the per-frame products (half-res RGB, tracking pyramid, search pyramid) of the next set_reference /
+    // add_frame are already in L.refHalf.. / L.movHalf.. (the stream keeps them per frame and swaps the descriptors in)
+    bool refPrepared, movPrepared;
+    // joint mode (stage C): tile shifts of the frame being aligned come from the minimiser instead of the tracker
+    const Img* givenShifts;
+    std::vector<float> jointHost;  // host staging of the joint mode's design matrix / pointer table (must outlive the copies)
     // optional per-launch timing of the accumulate kernel (bench.py roofline leg)
     bool timing;
     int nEvents;
@@ -399,6 +406,8 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
             return MFSR_E_NODEVICE;
         }
     }
+    b->refPrepared = b->movPrepared = false;
+    b->givenShifts = nullptr;
     b->copyStream = nullptr;
     b->upCounter = b->refCounter = 0;
     b->refHost = b->refDev = nullptr;
@@ -513,7 +522,7 @@ extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, m
     TRY(flush_pending(b, stream, false));  // a frame still waiting belongs to the previous reference
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
-    TRY(prepare_frame(b, rawRef, L.refHalf, L.refPyr, stream));
+    if (!b->refPrepared) TRY(prepare_frame(b, rawRef, L.refHalf, L.refPyr, stream));
     if (c.fused)
         for (int l = 0; l < c.levels; l++) {
             const Img& ref = L.refPyr[ilog2(c.levelFactor[l])];
@@ -523,7 +532,8 @@ extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, m
 
     if (c.preAlign) {
         TRY(mfsr_preAlign_init(L.preWork, c.preAlignMaxAngle, stream));
-        TRY(mfsr_preAlignPyramid((const float*)L.refPyr[0].ptr, L.tw, L.th, L.refPyr[0].pitch, L.preRefPyr, stream));
+        if (!b->refPrepared)
+            TRY(mfsr_preAlignPyramid((const float*)L.refPyr[0].ptr, L.tw, L.th, L.refPyr[0].pitch, L.preRefPyr, stream));
     }
 
     // E: kernel shape field from the reference tracking image
@@ -725,17 +735,13 @@ static int flush_pending(mfsr_burst* b, mfsr_stream_t stream, bool materializeFr
     return join_fuse(b, stream);
 }
 
-extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float3* imgOut,
-                                    mfsr_float3* totalWeights, mfsr_stream_t stream)
+// A1 + (I) + B + D + F of one frame into ring slot `slot`: *flowOut / *maskOut name the buffers that hold the result
+static int align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, int slot, Img** flowOut, Img** maskOut,
+                       mfsr_stream_t stream)
 {
-    MFSR_REQUIRE(b && raw && imgOut && totalWeights);
-    MFSR_REQUIRE(b->haveRef);
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
-    TRY(mfsr_set_cfa_pattern(c.cfa));
-
-    // ring slot of this frame; its buffers are free once the fuse that read them last has run
-    const int slot = b->frameCounter++ % kRing;
+    // the slot's buffers are free once the fuse that read them last has run
     if (b->fuseStream && b->fusedOutstanding[slot]) {
         MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evFused[slot], 0));
         b->fusedOutstanding[slot] = false;
@@ -748,12 +754,13 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
         MFSR_HIP_TRY(hipMemsetAsync(flow->ptr, 0, (size_t)flow->pitch * flow->h, mfsr_s(stream)));
         TRY(mfsr_fill_f32((float*)mask->ptr, (size_t)mask->pitch / 4 * mask->h, 1.0f, stream));
     } else {
-        TRY(prepare_frame(b, raw, L.movHalf, L.movPyr, stream));
+        if (!b->movPrepared) TRY(prepare_frame(b, raw, L.movHalf, L.movPyr, stream));
         // I: global pre-alignment (base shift + rotation of this frame against the reference), kept in device memory
         mfsr_prealign hostBase;
         const mfsr_prealign* hb = nullptr;
         if (c.preAlign) {
-            TRY(mfsr_preAlignPyramid((const float*)L.movPyr[0].ptr, L.tw, L.th, L.movPyr[0].pitch, L.preMovPyr, stream));
+            if (!b->movPrepared)
+                TRY(mfsr_preAlignPyramid((const float*)L.movPyr[0].ptr, L.tw, L.th, L.movPyr[0].pitch, L.preMovPyr, stream));
             TRY(mfsr_preAlign(L.preRefPyr, L.preMovPyr, L.tw, L.th, c.preAlignMaxAngle, L.preWork, L.preResult, stream));
             if (!c.fused) {
                 // the reference-shaped entry points take baseShift / baseRotation by value: one host round trip
@@ -762,11 +769,12 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
                 hb = &hostBase;
             }
         }
-        TRY(track_tiles(b, hb, stream));
+        if (!b->givenShifts) TRY(track_tiles(b, hb, stream));
         const int last = c.levels - 1;
+        const Img& tileShifts = b->givenShifts ? *b->givenShifts : L.shifts[last];
         const mfsr_float2 zero2 = {0.0f, 0.0f};
         if (c.preAlign && c.fused) {
-            TRY(mfsr_CreateFlowFieldFromTilesBase((mfsr_float2*)flow->ptr, as_tex(L.shifts[last]), L.tw, L.th, flow->pitch,
+            TRY(mfsr_CreateFlowFieldFromTilesBase((mfsr_float2*)flow->ptr, as_tex(tileShifts), L.tw, L.th, flow->pitch,
                                                   L.preResult, stream));
         } else {
             mfsr_float2 base = zero2;
@@ -776,7 +784,7 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
                 base.y = hb->shiftY;
                 rot = hb->rotation;
             }
-            TRY(mfsr_CreateFlowFieldFromTiles((mfsr_float2*)flow->ptr, as_tex(L.shifts[last]), c.tileSize[last], L.tcx[last],
+            TRY(mfsr_CreateFlowFieldFromTiles((mfsr_float2*)flow->ptr, as_tex(tileShifts), c.tileSize[last], L.tcx[last],
                                               L.tcy[last], L.tw, L.th, flow->pitch, base, rot, stream));
         }
         for (int it = 0; it < c.lkIterations; it++) {
@@ -804,11 +812,32 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
         if (L.flowScale != 1 && !(c.fused && c.lkIterations > 0))  // the fused LK scales on its last iteration
             TRY(mfsr_scaleFlow((mfsr_float2*)flow->ptr, flow->pitch, L.tw, L.th, (float)L.flowScale, stream));
         // F: robustness mask (the 1-px ring is never written by the kernel -> zero it)
-        TRY(mfsr_zeroRing_f32x4((mfsr_float4*)mask->ptr, mask->pitch, L.hw, L.hh, stream));
-        TRY(mfsr_ComputeRobustnessMask((const mfsr_float3*)L.refHalf.ptr, (const mfsr_float3*)L.movHalf.ptr,
-                                       (mfsr_float4*)mask->ptr, as_tex(*flow), L.hw, L.hh, L.refHalf.pitch, mask->pitch,
-                                       c.alpha, c.beta, c.thresholdM, stream));
+        if (c.fused) {
+            TRY(mfsr_robustnessMaskFused((const mfsr_float3*)L.refHalf.ptr, (const mfsr_float3*)L.movHalf.ptr,
+                                         (mfsr_float4*)mask->ptr, as_tex(*flow), L.hw, L.hh, L.refHalf.pitch, mask->pitch, c.alpha,
+                                         c.beta, c.thresholdM, stream));
+        } else {
+            TRY(mfsr_zeroRing_f32x4((mfsr_float4*)mask->ptr, mask->pitch, L.hw, L.hh, stream));
+            TRY(mfsr_ComputeRobustnessMask((const mfsr_float3*)L.refHalf.ptr, (const mfsr_float3*)L.movHalf.ptr,
+                                           (mfsr_float4*)mask->ptr, as_tex(*flow), L.hw, L.hh, L.refHalf.pitch, mask->pitch,
+                                           c.alpha, c.beta, c.thresholdM, stream));
+        }
     }
+    *flowOut = flow;
+    *maskOut = mask;
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float3* imgOut,
+                                    mfsr_float3* totalWeights, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && raw && imgOut && totalWeights);
+    MFSR_REQUIRE(b->haveRef);
+    const mfsr_config& c = b->cfg;
+    TRY(mfsr_set_cfa_pattern(c.cfa));
+    const int slot = b->frameCounter++ % kRing;
+    Img *flow = nullptr, *mask = nullptr;
+    TRY(align_frame(b, raw, isReference, slot, &flow, &mask, stream));
     b->flowCur = flow;
     b->maskCur = mask;
     if (b->fuseStream) MFSR_HIP_TRY(hipEventRecord(b->evAligned[slot], mfsr_s(stream)));
@@ -830,6 +859,114 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
         return MFSR_OK;
     }
     return accumulate_frames(b, 1, slot, -1, raw, nullptr, flow, nullptr, mask, nullptr, imgOut, totalWeights, stream);
+}
+
+// ---- building blocks of stripe-sharded bursts (multi-GPU: frames are aligned where they live, every rank fuses ALL
+//      frames onto its own stripe of HR rows; csrc/dist.cpp and the Python mirror drive these) -----------------------
+extern "C" int mfsr_burst_field_dims(const mfsr_burst* b, int* flowW, int* flowH, int* maskW, int* maskH)
+{
+    MFSR_REQUIRE(b != nullptr);
+    if (flowW) *flowW = b->L.tw;
+    if (flowH) *flowH = b->L.th;
+    if (maskW) *maskW = b->L.hw;
+    if (maskH) *maskH = b->L.hh;
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_burst_align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float2* flowOut, int flowPitch,
+                                      mfsr_float4* maskOut, int maskPitch, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && raw && flowOut && maskOut);
+    MFSR_REQUIRE(b->haveRef);
+    Layout& L = b->L;
+    MFSR_REQUIRE((long long)flowPitch >= 8LL * L.tw && (flowPitch & 7) == 0 && ((uintptr_t)flowOut & 7) == 0);
+    MFSR_REQUIRE((long long)maskPitch >= 16LL * L.hw && (maskPitch & 15) == 0 && ((uintptr_t)maskOut & 15) == 0);
+    TRY(mfsr_set_cfa_pattern(b->cfg.cfa));
+    const int slot = b->frameCounter++ % kRing;
+    Img *flow = nullptr, *mask = nullptr;
+    TRY(align_frame(b, raw, isReference, slot, &flow, &mask, stream));
+    b->flowCur = flow;
+    b->maskCur = mask;
+    MFSR_HIP_TRY(hipMemcpy2DAsync(flowOut, flowPitch, flow->ptr, flow->pitch, (size_t)L.tw * 8, L.th, hipMemcpyDeviceToDevice,
+                                  mfsr_s(stream)));
+    MFSR_HIP_TRY(hipMemcpy2DAsync(maskOut, maskPitch, mask->ptr, mask->pitch, (size_t)L.hw * 16, L.hh, hipMemcpyDeviceToDevice,
+                                  mfsr_s(stream)));
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_burst_fuse_rows(mfsr_burst* b, int nFrames, const uint16_t* const* raws, const mfsr_float2* const* flows,
+                                    int flowPitch, const mfsr_float4* const* masks, int maskPitch, mfsr_float3* imgOut,
+                                    mfsr_float3* totalWeights, int accumulatorsUndefined, int rowBegin, int rowEnd,
+                                    mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && raws && flows && masks && imgOut && totalWeights && nFrames >= 1 && nFrames <= 2);
+    MFSR_REQUIRE(b->haveRef);
+    const mfsr_config& c = b->cfg;
+    Layout& L = b->L;
+    const mfsr_float3 white = {c.white[0], c.white[1], c.white[2]};
+    const mfsr_float3 black = {c.black[0], c.black[1], c.black[2]};
+    TRY(mfsr_set_cfa_pattern(c.cfa));
+    mfsr_tex2d sh[2];
+    for (int n = 0; n < nFrames; n++) {
+        sh[n].ptr = flows[n];
+        sh[n].pitch = flowPitch;
+        sh[n].width = L.tw;
+        sh[n].height = L.th;
+    }
+    const bool timed = b->timing && b->nEvents < kMaxTimedLaunches;
+    if (timed) {
+        const int i = b->nEvents;
+        if (!b->evStart[i]) MFSR_HIP_TRY(hipEventCreate(&b->evStart[i]));
+        if (!b->evStop[i]) MFSR_HIP_TRY(hipEventCreate(&b->evStop[i]));
+        MFSR_HIP_TRY(hipEventRecord(b->evStart[i], mfsr_s(stream)));
+    }
+    TRY(mfsr_accumulateSuperResFullRows(nFrames, raws, imgOut, totalWeights, masks, as_tex(L.kparam4), sh, white, black, L.W, L.H,
+                                        c.scale, 12 * L.hrW, maskPitch, accumulatorsUndefined, rowBegin, rowEnd, stream));
+    if (timed) {
+        MFSR_HIP_TRY(hipEventRecord(b->evStop[b->nEvents], mfsr_s(stream)));
+        b->nEvents++;
+        b->nFramesTimed += nFrames;
+    }
+    return MFSR_OK;
+}
+
+// Stripe plan of rank `rank` of `worldSize`: its HR rows and the rows of every per-frame product its fuse reads.
+// Pure host arithmetic (no device), shared by csrc/dist.cpp and the Python mirror so that both exchange the same rows.
+extern "C" int mfsr_dist_stripe_plan(const mfsr_config* cfg, int worldSize, int rank, int rawHalo, mfsr_stripe_plan* out)
+{
+    MFSR_REQUIRE(out != nullptr && worldSize >= 1 && rank >= 0 && rank < worldSize && rawHalo >= 4);
+    TRY(validate(cfg));
+    const int s = cfg->scale, W = cfg->width, H = cfg->height;
+    const int hrH = s * H;
+    const int th = cfg->mono ? H : H / 2, hh = H / 2;
+    (void)W;
+    // stripes start on multiples of 16 HR rows (tile rows of every fuse kernel, mfsr_accumulateSuperResFullRows)
+    auto cut = [&](int g) { return g >= worldSize ? hrH : (int)((long long)hrH * g / worldSize / 16 * 16); };
+    const int r0 = cut(rank), r1 = cut(rank + 1);
+    memset(out, 0, sizeof(*out));
+    out->rowBegin = r0;
+    out->rowEnd = r1;
+    if (r1 <= r0) return MFSR_OK;  // more ranks than 16-row bands: this rank fuses nothing
+    // a field with fh rows is sampled at HR row Y through rows floor((Y + .5) * fh / hrH - .5) and the next one
+    auto rows_of = [&](int fh, int pad, int* first, int* count) {
+        const int per = hrH / fh;  // HR rows per field row (exact: validate() makes H a multiple of 4)
+        int a = r0 / per - 1 - pad, b = (r1 + per - 1) / per + 1 + pad;
+        if (a < 0) a = 0;
+        if (b > fh) b = fh;
+        *first = a;
+        *count = b - a;
+    };
+    rows_of(th, 0, &out->flowRow0, &out->flowRows);
+    rows_of(hh, 1, &out->maskRow0, &out->maskRows);  // + the 5x5 footprint: site (Y + py) / s / 2, |py| <= 2
+    {
+        int a = r0 / s - rawHalo, b = (r1 + s - 1) / s + rawHalo;  // raw row (Y + py + round(s * v)) / s: |v| <= rawHalo - 3
+        if (a < 0) a = 0;
+        if (b > H) b = H;
+        out->rawRow0 = a;
+        out->rawRows = b - a;
+    }
+    out->maxFlowY = (float)(rawHalo - 3);
+    return MFSR_OK;
 }
 
 extern "C" int mfsr_burst_begin(mfsr_burst* b, mfsr_float3* imgOut, mfsr_float3* totalWeights, mfsr_stream_t stream)
@@ -884,14 +1021,13 @@ extern "C" int mfsr_burst_finish_rows(mfsr_burst* b, const mfsr_float3* imgOut, 
     MFSR_REQUIRE(row0 >= 0 && rows > 0 && row0 + rows <= L.hrH);
     TRY(flush_pending(b, stream));
     const int pitch = 12 * L.hrW;
-    const float v0 = (float)row0 / (float)L.hrH, v1 = (float)(row0 + rows) / (float)L.hrH;
     const size_t off = (size_t)row0 * pitch;
-    return mfsr_finishFused((const mfsr_float3*)((const char*)imgOut + off),
-                            (const mfsr_float3*)((const char*)totalWeights + off), pitch,
-                            (const mfsr_float3*)L.fallback.ptr, L.fallback.pitch, L.W, L.H, 0.0f, 1.0f, v0, v1,
-                            outImg ? (mfsr_float3*)((char*)outImg + off) : nullptr, pitch,
-                            out16 ? out16 + (size_t)row0 * L.hrW * 3 : nullptr, L.hrW, rows, c.weightThreshold,
-                            c.applyGamma, 65535.0f, stream);
+    return mfsr_finishFusedRows((const mfsr_float3*)((const char*)imgOut + off),
+                                (const mfsr_float3*)((const char*)totalWeights + off), pitch,
+                                (const mfsr_float3*)L.fallback.ptr, L.fallback.pitch, L.W, L.H, 0.0f, 1.0f, 0.0f, 1.0f,
+                                outImg ? (mfsr_float3*)((char*)outImg + off) : nullptr, pitch,
+                                out16 ? out16 + (size_t)row0 * L.hrW * 3 : nullptr, L.hrW, rows, c.weightThreshold,
+                                c.applyGamma, 65535.0f, row0, L.hrH, stream);
 }
 
 // ---- host-frame bursts (cfg.uploadRing) --------------------------------------------------------------------------
@@ -963,6 +1099,450 @@ extern "C" int mfsr_burst_prealign_result(mfsr_burst* b, mfsr_prealign* hostOut,
     MFSR_REQUIRE(b->cfg.preAlign && b->L.preResult);
     MFSR_HIP_TRY(hipMemcpyAsync(hostOut, b->L.preResult, sizeof(*hostOut), hipMemcpyDeviceToHost, mfsr_s(stream)));
     MFSR_HIP_TRY(hipStreamSynchronize(mfsr_s(stream)));
+    return MFSR_OK;
+}
+
+// ---- frame streams: sliding window of 2R+1 frames around every frame (the reference's setTemporalAreaRadius(1),
+//      finalProject/Project/multi_frame_sr.cpp:182; BASELINE configs[4]) ---------------------------------------------------
+// Output t fuses frames [t-R, t+R] (clipped to the stream) with frame t as the reference: what one mfsr_burst_* burst per
+// window computes.  A frame takes part in up to 2R+1 windows; its upload and its per-frame products that do not depend
+// on the reference (A1 half-resolution RGB, tracking pyramid, pre-alignment search pyramid) are made once, when it
+// arrives, and kept in a ring of 2R+1 entries; the burst context gets their descriptors swapped in.
+namespace {
+struct FrameProducts {
+    uint16_t* raw;
+    Img half;
+    Img pyr[8];
+    void* prePyr;
+};
+struct StreamLayout {
+    size_t burstWs, accBytes, entryBytes;
+    size_t offBurst, offImg, offTw, offEntries, total;
+};
+size_t stream_entry(const mfsr_config* c, char* base, FrameProducts* fp)
+{
+    Layout L;
+    make_layout(c, nullptr, &L);
+    Bump b{base, 0};
+    const int nl = ilog2(L.maxFactor) + 1;
+    FrameProducts tmp;
+    memset((void*)&tmp, 0, sizeof(tmp));
+    tmp.raw = (uint16_t*)b.take((size_t)L.W * L.H * 2);
+    tmp.half = b.image(L.hw, L.hh, 12);
+    for (int i = 0; i < nl; i++) tmp.pyr[i] = b.image(L.tw >> i, L.th >> i, 4);
+    tmp.prePyr = c->preAlign ? b.take(mfsr_preAlign_pyramid_bytes(L.tw, L.th)) : nullptr;
+    if (fp) *fp = tmp;
+    return align_up(b.off, 256);
+}
+int stream_layout(const mfsr_config* c, int radius, StreamLayout* S)
+{
+    memset(S, 0, sizeof(*S));
+    Layout L;
+    make_layout(c, nullptr, &L);
+    S->burstWs = L.total;
+    S->accBytes = (size_t)12 * L.hrW * L.hrH;
+    S->entryBytes = stream_entry(c, nullptr, nullptr);
+    size_t off = 0;
+    S->offBurst = off;
+    off = align_up(off + S->burstWs, 256);
+    S->offImg = off;
+    off = align_up(off + S->accBytes, 256);
+    S->offTw = off;
+    off = align_up(off + S->accBytes, 256);
+    S->offEntries = off;
+    off += S->entryBytes * (size_t)(2 * radius + 1);
+    S->total = align_up(off, 256);
+    return MFSR_OK;
+}
+}  // namespace
+
+struct mfsr_stream {
+    mfsr_config cfg;
+    int R, cap, hostFrames;
+    mfsr_burst* b;
+    StreamLayout S;
+    mfsr_float3 *imgOut, *totalWeights;
+    std::vector<FrameProducts>* fp;
+    long long pushed, produced;
+    // frames in host memory: uploads on a stream of their own, ordered against the windows that read the slot
+    hipStream_t copyStream;
+    hipEvent_t evUp, evWindow[64];   // evWindow[j % 64]: output j's work enqueued on the compute stream
+    bool windowRecorded[64];
+};
+
+extern "C" size_t mfsr_stream_workspace_bytes(const mfsr_config* cfg, int radius)
+{
+    if (validate(cfg) != MFSR_OK || radius < 0 || radius > 15) return 0;
+    StreamLayout S;
+    stream_layout(cfg, radius, &S);
+    return S.total;
+}
+
+extern "C" int mfsr_stream_create(mfsr_stream** out, const mfsr_config* cfg, int radius, int framesInHostMemory, void* workspace,
+                                  size_t workspaceBytes)
+{
+    MFSR_REQUIRE(out && workspace && radius >= 0 && radius <= 15 && ((uintptr_t)workspace & 255) == 0);
+    TRY(validate(cfg));
+    mfsr_stream* s = new (std::nothrow) mfsr_stream;
+    MFSR_REQUIRE(s != nullptr);
+    memset((void*)s, 0, sizeof(*s));
+    s->cfg = *cfg;
+    s->cfg.frames = 2 * radius + 1;
+    s->cfg.uploadRing = 0;
+    s->R = radius;
+    s->cap = 2 * radius + 1;
+    s->hostFrames = framesInHostMemory ? 1 : 0;
+    stream_layout(&s->cfg, radius, &s->S);
+    if (s->S.total > workspaceBytes) {
+        fprintf(stderr, "mfsr: stream workspace too small: need %zu bytes, got %zu\n", s->S.total, workspaceBytes);
+        delete s;
+        return MFSR_E_WORKSPACE;
+    }
+    char* base = (char*)workspace;
+    int rc = mfsr_burst_create(&s->b, &s->cfg, base + s->S.offBurst, s->S.burstWs);
+    if (rc != MFSR_OK) {
+        delete s;
+        return rc;
+    }
+    s->imgOut = (mfsr_float3*)(base + s->S.offImg);
+    s->totalWeights = (mfsr_float3*)(base + s->S.offTw);
+    s->fp = new (std::nothrow) std::vector<FrameProducts>(s->cap);
+    for (int i = 0; i < s->cap; i++) stream_entry(&s->cfg, base + s->S.offEntries + s->S.entryBytes * (size_t)i, &(*s->fp)[i]);
+    if (s->hostFrames) {
+        hipError_t e = hipStreamCreateWithFlags(&s->copyStream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->evUp, hipEventDisableTiming);
+        for (int i = 0; i < 64 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&s->evWindow[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            mfsr_stream_destroy(s);
+            return MFSR_E_NODEVICE;
+        }
+    }
+    *out = s;
+    return MFSR_OK;
+}
+
+extern "C" void mfsr_stream_destroy(mfsr_stream* s)
+{
+    if (!s) return;
+    if (s->copyStream) (void)hipStreamSynchronize(s->copyStream);
+    if (s->evUp) (void)hipEventDestroy(s->evUp);
+    for (int i = 0; i < 64; i++)
+        if (s->evWindow[i]) (void)hipEventDestroy(s->evWindow[i]);
+    if (s->copyStream) (void)hipStreamDestroy(s->copyStream);
+    mfsr_burst_destroy(s->b);
+    delete s->fp;
+    delete s;
+}
+
+// output j from the cached frames [lo, hi]
+static int stream_window(mfsr_stream* s, long long j, long long lo, long long hi, mfsr_float3* outImg, uint16_t* out16,
+                         mfsr_stream_t stream)
+{
+    mfsr_burst* b = s->b;
+    Layout& L = b->L;
+    const int nl = ilog2(L.maxFactor) + 1;
+    auto use = [&](const FrameProducts& f, bool asRef) {
+        (asRef ? L.refHalf : L.movHalf) = f.half;
+        for (int i = 0; i < nl; i++) (asRef ? L.refPyr : L.movPyr)[i] = f.pyr[i];
+        (asRef ? L.preRefPyr : L.preMovPyr) = f.prePyr;
+    };
+    const FrameProducts& ref = (*s->fp)[j % s->cap];
+    TRY(mfsr_burst_begin(b, s->imgOut, s->totalWeights, stream));
+    use(ref, true);
+    b->refPrepared = true;
+    int rc = mfsr_burst_set_reference(b, ref.raw, stream);
+    b->refPrepared = false;
+    if (rc) return rc;
+    for (long long k = lo; k <= hi && rc == MFSR_OK; k++) {
+        const FrameProducts& f = (*s->fp)[k % s->cap];
+        use(f, false);
+        b->movPrepared = true;
+        rc = mfsr_burst_add_frame(b, f.raw, k == j, s->imgOut, s->totalWeights, stream);
+        b->movPrepared = false;
+    }
+    if (rc) return rc;
+    TRY(mfsr_burst_finish(b, s->imgOut, s->totalWeights, outImg, out16, stream));
+    if (s->copyStream) {
+        MFSR_HIP_TRY(hipEventRecord(s->evWindow[j % 64], mfsr_s(stream)));
+        s->windowRecorded[j % 64] = true;
+    }
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_stream_push(mfsr_stream* s, const uint16_t* frame, mfsr_float3* outImg, uint16_t* out16, long long* produced,
+                                mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(s && frame && produced);
+    *produced = -1;
+    mfsr_burst* b = s->b;
+    Layout& L = b->L;
+    const long long t = s->pushed;
+    FrameProducts& f = (*s->fp)[t % s->cap];
+    const size_t rawBytes = (size_t)L.W * L.H * 2;
+    if (s->hostFrames) {
+        // the slot held frame t - cap, last read by output t - cap + R = t - R - 1
+        const long long last = t - s->R - 1;
+        if (last >= 0 && s->windowRecorded[last % 64]) MFSR_HIP_TRY(hipStreamWaitEvent(s->copyStream, s->evWindow[last % 64], 0));
+        MFSR_HIP_TRY(hipMemcpyAsync(f.raw, frame, rawBytes, hipMemcpyHostToDevice, s->copyStream));
+        MFSR_HIP_TRY(hipEventRecord(s->evUp, s->copyStream));
+        MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), s->evUp, 0));
+    } else {
+        MFSR_HIP_TRY(hipMemcpyAsync(f.raw, frame, rawBytes, hipMemcpyDeviceToDevice, mfsr_s(stream)));
+    }
+    // per-frame products, once per frame
+    TRY(mfsr_set_cfa_pattern(s->cfg.cfa));
+    TRY(prepare_frame(b, f.raw, f.half, f.pyr, stream));
+    if (s->cfg.preAlign)
+        TRY(mfsr_preAlignPyramid((const float*)f.pyr[0].ptr, L.tw, L.th, f.pyr[0].pitch, f.prePyr, stream));
+    s->pushed = t + 1;
+    if (t < s->R) return MFSR_OK;
+    MFSR_REQUIRE(outImg || out16);
+    const long long j = t - s->R;
+    TRY(stream_window(s, j, j - s->R > 0 ? j - s->R : 0, t, outImg, out16, stream));
+    s->produced = j + 1;
+    *produced = j;
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_stream_drain(mfsr_stream* s, mfsr_float3* outImg, uint16_t* out16, long long* produced, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(s && produced && (outImg || out16));
+    *produced = -1;
+    if (s->produced >= s->pushed) return MFSR_OK;
+    const long long j = s->produced;
+    TRY(stream_window(s, j, j - s->R > 0 ? j - s->R : 0, s->pushed - 1, outImg, out16, stream));
+    s->produced = j + 1;
+    *produced = j;
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_stream_reset(mfsr_stream* s)
+{
+    MFSR_REQUIRE(s != nullptr);
+    s->pushed = s->produced = 0;
+    return MFSR_OK;
+}
+
+// ---- whole burst with the joint shift minimiser (stage C of SURVEY.md section 3.3; ShiftMinimizerKernels.cu) ----------------
+// Besides every (reference, k) pair the tile tracker also measures every neighbouring pair (k, k+1); per tile the
+// N-1 frame-to-frame shifts are the least-squares solution of those m measurements (design matrix: a contiguous run of
+// ones per pair, ShiftMinimizerKernels.cu:137), pairs whose residual exceeds 1 px^2 are dropped one at a time and the
+// system is solved again (checkForOutliers :81-139), and the reference->k tile shifts are the signed prefix sums
+// (getOptimalShifts :179-218).  Those shifts then replace the tracker's in the per-frame chain D (flow field + LK) -> F -> G.
+// One fixed launch sequence, no host round trip: the solve/reject loop runs per tile inside mfsr_minimizeShiftsFused.
+namespace {
+struct JointLayout {
+    int N, m, n1, tiles, tcx, tcy;
+    size_t entryBytes;
+    size_t offEntries, offPairShifts, offRefSq, offMatrix, offMeasured, offOneToOne, offOptimT, offStatus, offInfo, offPtrs, offPitches,
+        offOptimal, total;
+    int pairPitch;
+    size_t pairBytes, refSqBytes;
+};
+int joint_pairs(int N, int ref, int (*pairs)[2])
+{
+    int m = 0;
+    for (int k = 0; k + 1 < N; k++) {  // neighbours first
+        if (pairs) {
+            pairs[m][0] = k;
+            pairs[m][1] = k + 1;
+        }
+        m++;
+    }
+    for (int k = 0; k < N; k++) {  // then the reference against every frame that is not its neighbour
+        const int a = k < ref ? k : ref, bb = k < ref ? ref : k;
+        if (bb - a < 2) continue;
+        if (pairs) {
+            pairs[m][0] = a;
+            pairs[m][1] = bb;
+        }
+        m++;
+    }
+    return m;
+}
+void joint_layout(const mfsr_config* c, JointLayout* J)
+{
+    memset(J, 0, sizeof(*J));
+    Layout L;
+    make_layout(c, nullptr, &L);
+    const int last = c->levels - 1;
+    J->N = c->frames;
+    J->n1 = c->frames - 1;
+    J->m = joint_pairs(c->frames, c->reference, nullptr);
+    J->tcx = L.tcx[last];
+    J->tcy = L.tcy[last];
+    J->tiles = J->tcx * J->tcy;
+    J->entryBytes = stream_entry(c, nullptr, nullptr);
+    J->pairPitch = (int)align_up((size_t)J->tcx * 8, 64);
+    J->pairBytes = align_up((size_t)J->pairPitch * J->tcy, 256);
+    size_t refSq = 0;
+    for (int l = 0; l < c->levels; l++) refSq += align_up((size_t)L.tcx[l] * L.tcy[l] * 4, 256);
+    J->refSqBytes = refSq;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        off = align_up(off, 256);
+        const size_t o = off;
+        off += bytes;
+        return o;
+    };
+    J->offEntries = take(J->entryBytes * (size_t)J->N);
+    J->offPairShifts = take(J->pairBytes * (size_t)J->m);
+    J->offRefSq = take(J->refSqBytes * (size_t)J->N);
+    J->offMatrix = take(sizeof(float) * (size_t)J->tiles * J->n1 * J->m);
+    J->offMeasured = take(8 * (size_t)J->tiles * J->m);
+    J->offOneToOne = take(8 * (size_t)J->tiles * J->n1);
+    J->offOptimT = take(sizeof(float) * 2 * (size_t)J->tiles * J->m);
+    J->offStatus = take(sizeof(int) * (size_t)J->tiles);
+    J->offInfo = take(sizeof(int) * (size_t)J->tiles);
+    J->offPtrs = take(sizeof(void*) * (size_t)J->m);
+    J->offPitches = take(sizeof(int) * (size_t)J->m);
+    J->offOptimal = take(J->pairBytes);
+    J->total = align_up(off, 256);
+}
+}  // namespace
+
+extern "C" size_t mfsr_burst_joint_workspace_bytes(const mfsr_config* cfg)
+{
+    if (validate(cfg) != MFSR_OK || cfg->frames < 2 || cfg->frames - 1 > 63) return 0;
+    JointLayout J;
+    joint_layout(cfg, &J);
+    return J.total;
+}
+
+extern "C" int mfsr_burst_process_joint(mfsr_burst* b, const uint16_t* const* frames, void* jointWorkspace, size_t jointBytes,
+                                        mfsr_float3* imgOut, mfsr_float3* totalWeights, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && frames && jointWorkspace && imgOut && totalWeights && ((uintptr_t)jointWorkspace & 255) == 0);
+    const mfsr_config& c = b->cfg;
+    Layout& L = b->L;
+    MFSR_REQUIRE(c.frames >= 2 && c.frames - 1 <= 63);
+    if (c.preAlign || !c.fused) {
+        fprintf(stderr, "mfsr: the joint mode needs cfg.fused = 1 and cfg.preAlign = 0 (the minimiser sums tracked shifts only)\n");
+        return MFSR_E_UNSUPPORTED;
+    }
+    JointLayout J;
+    joint_layout(&c, &J);
+    if (J.total > jointBytes) {
+        fprintf(stderr, "mfsr: joint workspace too small: need %zu bytes, got %zu\n", J.total, jointBytes);
+        return MFSR_E_WORKSPACE;
+    }
+    for (int k = 0; k < c.frames; k++) MFSR_REQUIRE(frames[k] != nullptr);
+    char* base = (char*)jointWorkspace;
+    const int N = c.frames, last = c.levels - 1, nl = ilog2(L.maxFactor) + 1;
+    std::vector<FrameProducts> fp(N);
+    TRY(mfsr_set_cfa_pattern(c.cfa));
+    TRY(flush_pending(b, stream, false));
+    // per-frame products of every frame (each serves as reference and as moved frame of some pair)
+    for (int k = 0; k < N; k++) {
+        stream_entry(&c, base + J.offEntries + J.entryBytes * (size_t)k, &fp[k]);
+        fp[k].raw = const_cast<uint16_t*>(frames[k]);  // read only
+        TRY(prepare_frame(b, frames[k], fp[k].half, fp[k].pyr, stream));
+    }
+    auto use = [&](const FrameProducts& f, bool asRef) {
+        (asRef ? L.refHalf : L.movHalf) = f.half;
+        for (int i = 0; i < nl; i++) (asRef ? L.refPyr : L.movPyr)[i] = f.pyr[i];
+    };
+    const Img savedRefHalf = L.refHalf, savedMovHalf = L.movHalf;
+    Img savedRefPyr[8], savedMovPyr[8];
+    float* savedRefSq[kMaxLevels];
+    for (int i = 0; i < 8; i++) {
+        savedRefPyr[i] = L.refPyr[i];
+        savedMovPyr[i] = L.movPyr[i];
+    }
+    for (int l = 0; l < kMaxLevels; l++) savedRefSq[l] = L.refSq[l];
+    auto restore = [&]() {
+        L.refHalf = savedRefHalf;
+        L.movHalf = savedMovHalf;
+        for (int i = 0; i < 8; i++) {
+            L.refPyr[i] = savedRefPyr[i];
+            L.movPyr[i] = savedMovPyr[i];
+        }
+        for (int l = 0; l < kMaxLevels; l++) L.refSq[l] = savedRefSq[l];
+        b->refPrepared = b->movPrepared = false;
+        b->givenShifts = nullptr;
+    };
+    struct Guard {
+        decltype(restore)& r;
+        ~Guard() { r(); }
+    } guard{restore};
+
+    // sum(ref^2) tables of every frame that is the first of a pair
+    int pairs[2 * 64][2];
+    const int m = joint_pairs(N, c.reference, pairs);
+    auto refsq_of = [&](int k, int l) {
+        size_t o = 0;
+        for (int i = 0; i < l; i++) o += align_up((size_t)L.tcx[i] * L.tcy[i] * 4, 256);
+        return (float*)(base + J.offRefSq + J.refSqBytes * (size_t)k + o);
+    };
+    std::vector<char> haveSq(N, 0);
+    // B: every pair through the coarse -> fine tracker
+    const float2* hostPtrs[2 * 64];
+    int hostPitches[2 * 64];
+    for (int p = 0; p < m; p++) {
+        const int a = pairs[p][0], bb = pairs[p][1];
+        use(fp[a], true);
+        use(fp[bb], false);
+        for (int l = 0; l < c.levels; l++) {
+            L.refSq[l] = refsq_of(a, l);
+            if (!haveSq[a]) {
+                const Img& ref = L.refPyr[ilog2(c.levelFactor[l])];
+                TRY(mfsr_tileSquaredSums((const float*)ref.ptr, L.refSq[l], ref.w, ref.h, ref.pitch, c.maxShift[l], c.tileSize[l],
+                                         L.tcx[l], L.tcy[l], stream));
+            }
+        }
+        haveSq[a] = 1;
+        TRY(track_tiles(b, nullptr, stream));
+        char* dst = base + J.offPairShifts + J.pairBytes * (size_t)p;
+        MFSR_HIP_TRY(hipMemcpy2DAsync(dst, J.pairPitch, L.shifts[last].ptr, L.shifts[last].pitch, (size_t)J.tcx * 8, J.tcy,
+                                      hipMemcpyDeviceToDevice, mfsr_s(stream)));
+        hostPtrs[p] = (const float2*)dst;
+        hostPitches[p] = J.pairPitch;
+    }
+    // C: [tile][m] measurements, design matrix, per-tile solve / reject loop, prefix sums
+    b->jointHost.assign((size_t)J.n1 * m + 2 * (size_t)m * sizeof(void*) / sizeof(float) + 2 * m + 8, 0.0f);
+    float* hA = b->jointHost.data();  // column-major m x n1 (ShiftMinimizerKernels.cu:137): row p has ones in columns a..b-1
+    for (int p = 0; p < m; p++)
+        for (int col = pairs[p][0]; col < pairs[p][1]; col++) hA[p + (size_t)col * m] = 1.0f;
+    char* hTail = (char*)(hA + (size_t)J.n1 * m);
+    hTail = (char*)(((uintptr_t)hTail + 15) & ~(uintptr_t)15);
+    memcpy(hTail, hostPtrs, sizeof(void*) * m);
+    memcpy(hTail + sizeof(void*) * m, hostPitches, sizeof(int) * m);
+    float* dA = (float*)(base + J.offMatrix);
+    MFSR_HIP_TRY(hipMemcpyAsync(dA, hA, sizeof(float) * (size_t)J.n1 * m, hipMemcpyHostToDevice, mfsr_s(stream)));
+    MFSR_HIP_TRY(hipMemcpyAsync(base + J.offPtrs, hTail, sizeof(void*) * m, hipMemcpyHostToDevice, mfsr_s(stream)));
+    MFSR_HIP_TRY(hipMemcpyAsync(base + J.offPitches, hTail + sizeof(void*) * m, sizeof(int) * m, hipMemcpyHostToDevice, mfsr_s(stream)));
+    TRY(mfsr_copyShiftMatrix(dA, J.tiles, N, m, stream));
+    mfsr_float2* measured = (mfsr_float2*)(base + J.offMeasured);
+    TRY(mfsr_concatenateShifts((const mfsr_float2* const*)(base + J.offPtrs), (int*)(base + J.offPitches), measured, m, J.tcx, J.tcy,
+                               stream));
+    mfsr_float2* oneToOne = (mfsr_float2*)(base + J.offOneToOne);
+    TRY(mfsr_minimizeShiftsFused(dA, measured, oneToOne, (float*)(base + J.offOptimT), (int*)(base + J.offStatus),
+                                 (int*)(base + J.offInfo), J.tiles, N, m, stream));
+    // D, F, G per frame with the minimiser's tile shifts
+    use(fp[c.reference], true);
+    for (int l = 0; l < c.levels; l++) L.refSq[l] = refsq_of(c.reference, l);  // (unused by the chain below; kept consistent)
+    b->refPrepared = true;
+    TRY(mfsr_burst_begin(b, imgOut, totalWeights, stream));
+    TRY(mfsr_burst_set_reference(b, frames[c.reference], stream));
+    // set_reference recomputed the reference's tile sums into L.refSq: harmless
+    Img optimal;
+    optimal.ptr = base + J.offOptimal;
+    optimal.pitch = J.pairPitch;
+    optimal.w = J.tcx;
+    optimal.h = J.tcy;
+    for (int k = 0; k < N; k++) {
+        if (k != c.reference) {
+            TRY(mfsr_getOptimalShifts((mfsr_float2*)optimal.ptr, oneToOne, N, J.tcx, J.tcy, optimal.pitch, c.reference, k, stream));
+            use(fp[k], false);
+            b->movPrepared = true;
+            b->givenShifts = &optimal;
+        }
+        const int rc = mfsr_burst_add_frame(b, frames[k], k == c.reference, imgOut, totalWeights, stream);
+        b->movPrepared = false;
+        b->givenShifts = nullptr;
+        if (rc) return rc;
+    }
+    TRY(mfsr_burst_flush(b, stream));
     return MFSR_OK;
 }
 

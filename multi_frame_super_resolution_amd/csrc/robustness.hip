@@ -115,6 +115,148 @@ __global__ void __launch_bounds__(256)
     row_ptr(robustnessMask, maskPitch, pxY)[pxX] = mask;
 }
 
+// ---- MI355X kernel ---------------------------------------------------------------------------------------------------
+// The straight kernel above is VALU-bound, not memory-bound (706 VALU instructions per pixel: IEEE sqrt / division
+// expansions, three ocml expf, two full bilinear fetches, 18 address computations; 38.9 us per 4K frame for 99.5 MB of
+// algorithmic traffic, 164 MB counted).  This one
+//  * stages the reference patch rows of a 64 x 8 tile (+1 halo) in LDS as three planes: the 27 reads of a pixel are
+//    LDS reads at compile-time offsets instead of nine 12-byte global gathers with their address arithmetic
+//    (HBM/L2 traffic of the reference image: once per tile instead of ~1.65x);
+//  * takes every square root, reciprocal and exponential on the hardware units (v_sqrt_f32, v_rcp_f32, v_exp_f32: 1 ulp)
+//    -- the mask is a continuous function of them, so the result moves by a few 1e-7 (test tolerance 2e-6); the two
+//    discontinuities (round(0.5 * flow), M > thresholdM) keep their exact arithmetic: the flow fetch is the bit-exact
+//    bilinear of the straight kernel and the means are summed in the reference's order and divided exactly;
+//  * reads the one live sample of the 5 x 5 flow loop (x = y = 2, :66) as a plain texel when the flow field has the
+//    image's resolution (the Bayer pipeline): the bilinear fetch lands on a texel centre up to 1 ulp of the coordinate;
+//  * writes the zero ring the reference leaves to its caller (:48-49): no separate ring launch.
+#define RB_TX 64
+#define RB_TY 8
+template <bool ALIGNED>
+__global__ void __launch_bounds__(RB_TX* RB_TY)
+    k_robustnessFused(const pix3* __restrict__ rawImgRef, const pix3* __restrict__ rawImgMoved, float4* __restrict__ robustnessMask,
+                      mfsr_tex2d texUV, int imgWidth, int imgHeight, int imgPitch, int maskPitch, float alpha, float beta,
+                      float thresholdM)
+{
+    __shared__ float sR[3][RB_TY + 2][RB_TX + 2];
+    const int lx = threadIdx.x, ly = threadIdx.y;
+    const int x0 = blockIdx.x * RB_TX, y0 = blockIdx.y * RB_TY;
+    for (int t = ly * RB_TX + lx; t < (RB_TY + 2) * (RB_TX + 2); t += RB_TX * RB_TY) {
+        const int r = t / (RB_TX + 2), c = t - r * (RB_TX + 2);
+        const int gy = clampi(y0 - 1 + r, 0, imgHeight - 1), gx = clampi(x0 - 1 + c, 0, imgWidth - 1);
+        const pix3 p = row_ptr(rawImgRef, imgPitch, gy)[gx];
+        sR[0][r][c] = p.x;
+        sR[1][r][c] = p.y;
+        sR[2][r][c] = p.z;
+    }
+    __syncthreads();
+    const int pxX = x0 + lx, pxY = y0 + ly;
+    if (pxX >= imgWidth || pxY >= imgHeight) return;
+    float4* out = row_ptr(robustnessMask, maskPitch, pxY) + pxX;
+    if (pxX < 1 || pxY < 1 || pxX >= imgWidth - 1 || pxY >= imgHeight - 1) {
+        *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+    const float2 shiftf =
+        tex2<ADDR_CLAMP>(texUV, ((float)pxX + 0.5f) / (float)imgWidth, ((float)pxY + 0.5f) / (float)imgHeight);
+    float2 s;
+    if (ALIGNED) {
+        s = row_ptr((const float2*)texUV.ptr, texUV.pitch, min(pxY + 2, imgHeight - 1))[min(pxX + 2, imgWidth - 1)];
+    } else {
+        s = tex2<ADDR_CLAMP>(texUV, ((float)pxX + (float)2 + 0.5f) / (float)imgWidth, ((float)pxY + (float)2 + 0.5f) / (float)imgHeight);
+    }
+    float2 maxShift, minShift;
+    maxShift.x = fmaxf(s.x, shiftf.x);
+    maxShift.y = fmaxf(s.y, shiftf.y);
+    minShift.x = fminf(s.x, shiftf.x);
+    minShift.y = fminf(s.y, shiftf.y);
+    const int shx = round2i(shiftf.x * 0.5f);
+    const int shy = round2i(shiftf.y * 0.5f);
+
+    // means in the reference's summation order (row-major from 0), exact division by 9
+    float pr[3][9];
+    float mr[3] = {0.0f, 0.0f, 0.0f}, mm[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int y = 0; y < 3; y++) {
+        const pix3* rm = row_ptr(rawImgMoved, imgPitch, clampi(pxY + shy + y - 1, 0, imgHeight - 1));
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                pr[c][y * 3 + x] = sR[c][ly + y][lx + x];
+                mr[c] += pr[c][y * 3 + x];
+            }
+            const pix3 p = rm[clampi(pxX + shx + x - 1, 0, imgWidth - 1)];
+            mm[0] += p.x;
+            mm[1] += p.y;
+            mm[2] += p.z;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        mr[c] = div9(mr[c]);
+        mm[c] = div9(mm[c]);
+    }
+    float meandist = fabsf(mr[0] - mm[0]) + fabsf(mr[1] - mm[1]) + fabsf(mr[2] - mm[2]);
+    meandist = div3(meandist);
+    const float hm = 0.5f * meandist;
+    const float ddx = maxShift.x * hm - minShift.x * hm, ddy = maxShift.y * hm - minShift.y * hm;
+    const float M = __builtin_amdgcn_sqrtf(ddx * ddx + ddy * ddy);
+    const float sc = (M > thresholdM) ? 0.0f : 1.5f;
+    float m3[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float sd2 = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 9; p++) {
+            const float d = pr[c][p] - mr[c];
+            sd2 = __builtin_fmaf(d, d, sd2);
+        }
+        sd2 = div9(sd2);                                            // variance of the reference patch
+        float smd2 = __builtin_fmaf(alpha, mr[c], beta);            // noise model variance (green: / 2, :131)
+        if (c == 1) smd2 *= 0.5f;
+        const float sg2 = fmaxf(smd2, sd2);                         // max(sigma_md, std)^2
+        float d = fabsf(mr[c] - mm[c]);
+        d = d * (sd2 * __builtin_amdgcn_rcpf(sd2 + smd2));          // Wiener shrink (:142-144); 0 * inf = NaN as in the reference
+        const float e = __builtin_amdgcn_exp2f(-(d * d) * __builtin_amdgcn_rcpf(sg2) * 1.44269504088896340736f);
+        m3[c] = fmaxf(fminf(__builtin_fmaf(sc, e, -0.12f), 1.0f), 0.0f);
+    }
+    *out = make_float4(m3[0], m3[1], m3[2], M);
+}
+
+// 0: the straight kernel (IEEE sqrt / division, ocml expf: tight parity tests); 1 (default): k_robustnessFused
+static int g_robustness_fast = 1;
+extern "C" int mfsr_set_robustness_fast(int enable)
+{
+    g_robustness_fast = enable ? 1 : 0;
+    return MFSR_OK;
+}
+
+// F1 + the zero ring in one launch (what the burst pipeline calls); falls back to ring + straight kernel when the fast
+// kernel is switched off
+extern "C" int mfsr_robustnessMaskFused(const mfsr_float3* rawImgRef, const mfsr_float3* rawImgMoved, mfsr_float4* robustnessMask,
+                                        mfsr_tex2d texUV, int imgWidth, int imgHeight, int imgPitch, int maskPitch, float alpha,
+                                        float beta, float thresholdM, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(rawImgRef && rawImgMoved && robustnessMask && imgWidth > 2 && imgHeight > 2);
+    MFSR_REQUIRE((long long)imgPitch >= 12LL * imgWidth && (imgPitch & 3) == 0);
+    MFSR_REQUIRE((long long)maskPitch >= 16LL * imgWidth && (maskPitch & 15) == 0 && ((uintptr_t)robustnessMask & 15) == 0);
+    MFSR_REQUIRE(mfsr_tex_ok(texUV, 8) && ((uintptr_t)texUV.ptr & 7) == 0 && (texUV.pitch & 7) == 0);
+    if (!g_robustness_fast) {
+        int rc = mfsr_zeroRing_f32x4(robustnessMask, maskPitch, imgWidth, imgHeight, stream);
+        if (rc) return rc;
+        return mfsr_ComputeRobustnessMask(rawImgRef, rawImgMoved, robustnessMask, texUV, imgWidth, imgHeight, imgPitch, maskPitch,
+                                          alpha, beta, thresholdM, stream);
+    }
+    dim3 block(RB_TX, RB_TY), grid(mfsr_cdiv(imgWidth, RB_TX), mfsr_cdiv(imgHeight, RB_TY));
+    if (texUV.width == imgWidth && texUV.height == imgHeight)
+        hipLaunchKernelGGL(k_robustnessFused<true>, grid, block, 0, mfsr_s(stream), (const pix3*)rawImgRef, (const pix3*)rawImgMoved,
+                           (float4*)robustnessMask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM);
+    else
+        hipLaunchKernelGGL(k_robustnessFused<false>, grid, block, 0, mfsr_s(stream), (const pix3*)rawImgRef, (const pix3*)rawImgMoved,
+                           (float4*)robustnessMask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM);
+    return mfsr_launch_status("robustnessMaskFused");
+}
+
 extern "C" int mfsr_ComputeRobustnessMask(const mfsr_float3* rawImgRef, const mfsr_float3* rawImgMoved,
                                           mfsr_float4* robustnessMask, mfsr_tex2d texUV, int imgWidth, int imgHeight,
                                           int imgPitch, int maskPitch, float alpha, float beta, float thresholdM,

@@ -87,21 +87,10 @@ extern "C" int mfsr_setPointers(float** shiftMatrixArray, float** shiftMatrixSaf
 }
 
 // ---- C5: checkForOutliers (:81-139), one wavefront per tile ----------------------
-__global__ void __launch_bounds__(256)
-    k_checkForOutliers(float2* __restrict__ measuredShifts, const float* __restrict__ optimShiftsT,
-                       float* __restrict__ shiftMatrix, int* __restrict__ status, const int* __restrict__ inversionInfo,
-                       int tileCount, int imageCount, int shiftCount)
+// one wavefront; returns the dropped row or -1 (what the reference writes to status[tile])
+__device__ __forceinline__ int check_tile(float2* measuredShifts, const float* optimShiftsT, float* shiftMatrix, int tile, int lane,
+                                          int n1, int m)
 {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (tile >= tileCount) return;
-    if (status[tile] < 0) return;
-    if (inversionInfo[tile] != 0) {
-        if (lane == 0) status[tile] = -1;
-        return;
-    }
-    const int n1 = imageCount - 1;
-    const int m = shiftCount;
     const size_t offsetMatrix = (size_t)(n1 * m) * tile;
     const size_t offsetAllVec = (size_t)m * tile;
     float mx = 1;  // threshold 1 px^2 (:109)
@@ -118,10 +107,27 @@ __global__ void __launch_bounds__(256)
     }
     wave_argmax(mx, idxMax);
     if (idxMax == 0x7fffffff) idxMax = -1;
-    if (lane == 0) status[tile] = idxMax;
-    if (idxMax == -1) return;
+    if (idxMax == -1) return -1;
     if (lane == 0) measuredShifts[offsetAllVec + idxMax] = make_float2(0.0f, 0.0f);
     for (int col = lane; col < n1; col += 64) shiftMatrix[offsetMatrix + idxMax + (size_t)col * m] = 0;
+    return idxMax;
+}
+
+__global__ void __launch_bounds__(256)
+    k_checkForOutliers(float2* __restrict__ measuredShifts, const float* __restrict__ optimShiftsT,
+                       float* __restrict__ shiftMatrix, int* __restrict__ status, const int* __restrict__ inversionInfo,
+                       int tileCount, int imageCount, int shiftCount)
+{
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile >= tileCount) return;
+    if (status[tile] < 0) return;
+    if (inversionInfo[tile] != 0) {
+        if (lane == 0) status[tile] = -1;
+        return;
+    }
+    const int idxMax = check_tile(measuredShifts, optimShiftsT, shiftMatrix, tile, lane, imageCount - 1, shiftCount);
+    if (lane == 0) status[tile] = idxMax;
 }
 
 extern "C" int mfsr_checkForOutliers(mfsr_float2* measuredShifts, const float* optimShiftsT, float* shiftMatrix,
@@ -265,12 +271,10 @@ extern "C" int mfsr_separateShifts(const mfsr_float2* shiftIn, mfsr_float2* cons
 // partial pivoting; the pivot search is a wavefront arg-max over |N[r][k]|,
 // r >= k, ties -> lowest row (same as a serial "strictly greater" scan).
 #define SOLVE_MAXN 63
-__global__ void __launch_bounds__(64)
-    k_solveShiftsBatched(const float* __restrict__ shiftMatrix, const float2* __restrict__ measuredShifts,
-                         float2* __restrict__ shiftsOneToOne, float* __restrict__ optimShiftsT,
-                         int* __restrict__ inversionInfo, int tileCount, int n1, int m)
+// one 64-lane workgroup per tile; returns the inversion info (0 or index of the zero pivot + 1)
+__device__ __forceinline__ int solve_tile(float* s_solve, const float* shiftMatrix, const float2* measuredShifts,
+                                          float2* shiftsOneToOne, float* optimShiftsT, int tile, int n1, int m)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_solve[];
     float* N = s_solve;           // n1*n1
     float* Inv = N + n1 * n1;     // n1*n1
     float* rx = Inv + n1 * n1;    // n1
@@ -279,8 +283,6 @@ __global__ void __launch_bounds__(64)
     float* dx = fcol + n1;        // n1
     float* dy = dx + n1;          // n1
     const int lane = threadIdx.x;
-    const int tile = blockIdx.x;
-    if (tile >= tileCount) return;
     const float* A = shiftMatrix + (size_t)tile * n1 * m;
     const float2* b = measuredShifts + (size_t)tile * m;
 
@@ -347,11 +349,10 @@ __global__ void __launch_bounds__(64)
 
     float2* d = shiftsOneToOne + (size_t)tile * n1;
     float* o = optimShiftsT + (size_t)tile * 2 * m;
-    if (lane == 0) inversionInfo[tile] = info;
     if (info != 0) {
         for (int i = lane; i < n1; i += 64) d[i] = make_float2(0.0f, 0.0f);
         for (int r = lane; r < 2 * m; r += 64) o[r] = 0;
-        return;
+        return info;
     }
     for (int i = lane; i < n1; i += 64) {
         float sx = 0, sy = 0;
@@ -374,6 +375,49 @@ __global__ void __launch_bounds__(64)
         o[r] = sx;
         o[r + m] = sy;
     }
+    return 0;
+}
+
+__global__ void __launch_bounds__(64)
+    k_solveShiftsBatched(const float* __restrict__ shiftMatrix, const float2* __restrict__ measuredShifts,
+                         float2* __restrict__ shiftsOneToOne, float* __restrict__ optimShiftsT,
+                         int* __restrict__ inversionInfo, int tileCount, int n1, int m)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_solve[];
+    const int tile = blockIdx.x;
+    if (tile >= tileCount) return;
+    const int info = solve_tile(s_solve, shiftMatrix, measuredShifts, shiftsOneToOne, optimShiftsT, tile, n1, m);
+    if (threadIdx.x == 0) inversionInfo[tile] = info;
+}
+
+// C driver on the device: the tiles are independent problems, so the "solve -> checkForOutliers until converged" loop of
+// mfsr_minimizeShifts (one host round trip per round) runs inside ONE launch, one wavefront per tile, with no host
+// synchronisation: graph-capturable, and bit-identical to the host-driven loop (same statements per tile).
+__global__ void __launch_bounds__(64)
+    k_minimizeShiftsFused(float* shiftMatrix, float2* measuredShifts, float2* shiftsOneToOne, float* optimShiftsT, int* status,
+                          int* inversionInfo, int tileCount, int n1, int m)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_solve[];
+    const int tile = blockIdx.x;
+    if (tile >= tileCount) return;
+    int st = 0, info = 0;
+    for (int round = 0; round < m + 1; round++) {
+        info = solve_tile(s_solve, shiftMatrix, measuredShifts, shiftsOneToOne, optimShiftsT, tile, n1, m);
+        __threadfence_block();
+        __syncthreads();
+        if (info != 0) {
+            st = -1;
+            break;
+        }
+        st = check_tile(measuredShifts, optimShiftsT, shiftMatrix, tile, threadIdx.x, n1, m);
+        __threadfence_block();
+        __syncthreads();
+        if (st == -1) break;
+    }
+    if (threadIdx.x == 0) {
+        status[tile] = st;
+        inversionInfo[tile] = info;
+    }
 }
 
 extern "C" int mfsr_solveShiftsBatched(const float* shiftMatrix, const mfsr_float2* measuredShifts,
@@ -390,4 +434,20 @@ extern "C" int mfsr_solveShiftsBatched(const float* shiftMatrix, const mfsr_floa
                        (const float2*)measuredShifts, (float2*)shiftsOneToOne, optimShiftsT, inversionInfo, tileCount, n1,
                        shiftCount);
     return mfsr_launch_status("solveShiftsBatched");
+}
+
+
+extern "C" int mfsr_minimizeShiftsFused(float* shiftMatrix, mfsr_float2* measuredShifts, mfsr_float2* shiftsOneToOne,
+                                        float* optimShiftsT, int* status, int* inversionInfo, int tileCount, int imageCount,
+                                        int shiftCount, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(shiftMatrix && measuredShifts && shiftsOneToOne && optimShiftsT && status && inversionInfo);
+    MFSR_REQUIRE(tileCount > 0 && imageCount > 1 && shiftCount > 0);
+    MFSR_REQUIRE(((uintptr_t)measuredShifts & 7) == 0 && ((uintptr_t)shiftsOneToOne & 7) == 0);
+    const int n1 = imageCount - 1;
+    if (n1 > SOLVE_MAXN) return MFSR_E_UNSUPPORTED;
+    const size_t lds = sizeof(float) * ((size_t)2 * n1 * n1 + 5 * n1);
+    hipLaunchKernelGGL(k_minimizeShiftsFused, dim3(tileCount), dim3(64), lds, mfsr_s(stream), shiftMatrix, (float2*)measuredShifts,
+                       (float2*)shiftsOneToOne, optimShiftsT, status, inversionInfo, tileCount, n1, shiftCount);
+    return mfsr_launch_status("minimizeShiftsFused");
 }

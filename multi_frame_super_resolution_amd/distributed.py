@@ -8,7 +8,14 @@ LR-sized); ``imgOut`` / ``totalWeights`` are plain sums over frames
 sum of the HR accumulators.  The reference itself is single-GPU
 (``cudaSetDevice(0)``, kernel.cu:45): this module is new work.
 
-Two exchange modes:
+Three exchange modes (``stripes`` is what ``include/mfsr_dist.h`` / ``csrc/dist.cpp`` do with RCCL directly; this
+module is the torch.distributed mirror over the same C-ABI building blocks, which the world-2 tests drive with gloo):
+
+``stripes``         (default) the FUSE stage is sharded over HR row stripes instead of over frames: every rank aligns
+                    its own frames, sends each peer the rows of raw / flow / certainty that the peer's stripe reads
+                    (point-to-point, a few MB per message, all 7 xGMI links of a GPU busy at once), fuses ALL frames in
+                    frame order onto its stripe, finishes it, and rank 0 collects the u16 stripes.  ~20x less traffic
+                    than summing accumulators, and bit-identical to the single-GPU burst (same summation order).
 
 ``reduce``          ``reduce(sum)`` of both accumulators onto rank 0, which then
                     runs the finish stage on the whole HR grid (what north_star
@@ -134,11 +141,126 @@ def _reduce_scatter_rows(acc: torch.Tensor, rows: int, rank: int, world: int, gr
     out.copy_(tmp)
 
 
+class StripeBuffers:
+    """Per-frame products of a whole burst on one rank (flow, certainty, raw of frames owned elsewhere), allocated once
+    per context."""
+
+    def __init__(self, pipe, n_frames: int, rank: int, world: int):
+        self.flow, self.mask, self.raw = [], [], {}
+        for k in range(n_frames):
+            f, m = pipe.new_frame_products()
+            self.flow.append(f)
+            self.mask.append(m)
+            if k % world != rank:
+                self.raw[k] = torch.empty(pipe.cfg.height, pipe.cfg.width, dtype=torch.int16, device=pipe.device)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=pipe.device)
+
+
+def _p2p(ops, group):
+    """Run a list of (kind, tensor, peer) with kind in {"send", "recv"}: batched isend/irecv on RCCL; host-staged,
+    pairwise ordered blocking calls on gloo (CPU tests / rehearsals with fewer GPUs than ranks)."""
+    if not ops:
+        return
+    if not _staged(group):
+        reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend if k == "send" else dist.irecv, t, p, group) for k, t, p in ops])
+        for r in reqs:
+            r.wait()
+        return
+    me = dist.get_rank(group)
+    peers = sorted({p for _, _, p in ops})
+    for p in peers:                       # one peer at a time; the lower rank sends first
+        mine = [(k, t) for k, t, q in ops if q == p]
+        order = ("send", "recv") if me < p else ("recv", "send")
+        for phase in order:
+            for k, t in mine:
+                if k != phase:
+                    continue
+                if k == "send":
+                    dist.send(t.cpu().contiguous(), dst=p, group=group)
+                else:
+                    h = torch.empty(t.shape, dtype=t.dtype)
+                    dist.recv(h, src=p, group=group)
+                    t.copy_(h)
+
+
+def process_burst_stripes(pipe, frames, bufs: Optional[StripeBuffers] = None, group=None, n_frames: Optional[int] = None,
+                          raw_halo: int = 64):
+    """STRIPES mode (see the module docstring; mirrors csrc/dist.cpp::process_stripes).  ``frames`` maps global frame
+    number -> raw tensor for this rank's frames and the reference.  Returns (u16 HR image on rank 0 else None, status):
+    status 1 = a vertical flow exceeded the raw halo (result invalid)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = len(frames) if n_frames is None else n_frames
+    ref = pipe.cfg.reference
+    if bufs is None:
+        bufs = StripeBuffers(pipe, n, rank, world)
+    plans = [pipe.stripe_plan(world, p, raw_halo) for p in range(world)]
+    mine = plans[rank]
+    bufs.flag.zero_()
+    pipe.set_reference(frames[ref])
+    raws = {}
+    for k in range(rank, n, world):
+        raws[k] = frames[k]
+        pipe.align_frame(frames[k], k == ref, bufs.flow[k], bufs.mask[k])
+    if world > 1:
+        ops = []
+        for p in range(world):
+            pl = plans[p]
+            if p == rank or pl.rowEnd <= pl.rowBegin:
+                continue
+            for k in range(rank, n, world):
+                ops.append(("send", raws[k][pl.rawRow0:pl.rawRow0 + pl.rawRows], p))
+                ops.append(("send", bufs.flow[k][pl.flowRow0:pl.flowRow0 + pl.flowRows], p))
+                ops.append(("send", bufs.mask[k][pl.maskRow0:pl.maskRow0 + pl.maskRows], p))
+        if mine.rowEnd > mine.rowBegin:
+            for k in range(n):
+                owner = k % world
+                if owner == rank:
+                    continue
+                raws[k] = bufs.raw[k]
+                ops.append(("recv", bufs.raw[k][mine.rawRow0:mine.rawRow0 + mine.rawRows], owner))
+                ops.append(("recv", bufs.flow[k][mine.flowRow0:mine.flowRow0 + mine.flowRows], owner))
+                ops.append(("recv", bufs.mask[k][mine.maskRow0:mine.maskRow0 + mine.maskRows], owner))
+        _p2p(ops, group)
+    out16 = None
+    if mine.rowEnd > mine.rowBegin:
+        for k in range(n if mine.rawRows < pipe.cfg.height else 0):   # a whole-frame halo needs no check
+            pipe.check_flow_bound(bufs.flow[k][mine.flowRow0:mine.flowRow0 + mine.flowRows], float(mine.maxFlowY), bufs.flag)
+        per = 2 if pipe.cfg.pairFrames else 1
+        for k in range(0, n, per):
+            ks = list(range(k, min(k + per, n)))
+            pipe.fuse_rows([raws[j] for j in ks], [bufs.flow[j] for j in ks], [bufs.mask[j] for j in ks], mine.rowBegin,
+                           mine.rowEnd, fresh=(k == 0))
+        out16 = pipe.finish_rows(mine.rowBegin, mine.rowEnd - mine.rowBegin)
+    else:
+        out16 = pipe.out16
+    if world > 1:
+        out8 = out16.view(torch.uint8)
+        ops = []
+        if rank == 0:
+            for p in range(1, world):
+                pl = plans[p]
+                if pl.rowEnd > pl.rowBegin:
+                    ops.append(("recv", out8[pl.rowBegin:pl.rowEnd], p))
+        elif mine.rowEnd > mine.rowBegin:
+            ops.append(("send", out8[mine.rowBegin:mine.rowEnd], 0))
+        _p2p(ops, group)
+        if _staged(group):
+            h = bufs.flag.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+            bufs.flag.copy_(h)
+        else:
+            dist.all_reduce(bufs.flag, op=dist.ReduceOp.MAX, group=group)
+    return (out16 if rank == 0 else None), bufs.flag
+
+
 def process_burst(pipe, frames, mode: str = "auto", group=None, n_frames: Optional[int] = None):
     """Whole burst, frame-sharded over the ranks of ``group``; u16 HR image on rank 0."""
     if not dist.is_initialized():
         accumulate_local(pipe, frames, 0, 1, n_frames)
         _, out16 = pipe.finish(want_float=False, want_u16=True)
         return out16
+    if mode == "stripes":
+        return process_burst_stripes(pipe, frames, None, group, n_frames)[0]
     accumulate_local(pipe, frames, dist.get_rank(group), dist.get_world_size(group), n_frames)
     return exchange_and_finish(pipe, mode, group)

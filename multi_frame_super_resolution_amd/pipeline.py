@@ -122,6 +122,60 @@ class BurstPipeline:
             self.add_frame(frames[k], k == ref)
         return self.finish()
 
+    def process_joint(self, frames: Sequence[torch.Tensor]):
+        """Whole burst with the joint shift minimiser in the loop (mfsr_burst_process_joint: every neighbouring pair is
+        measured besides the (reference, k) pairs; per-tile least squares with outlier rejection gives the tile shifts)."""
+        if len(frames) != self.cfg.frames:
+            raise ValueError("process_joint needs exactly cfg.frames frames")
+        for f in frames:
+            self._check_raw(f)
+        nbytes = self.L.burst_joint_workspace_bytes(ctypes.byref(self.cfg))
+        if nbytes == 0:
+            raise ValueError("the joint mode needs 2 <= frames <= 64")
+        if getattr(self, "_joint_ws", None) is None or self._joint_ws.numel() < nbytes + 256:
+            self._joint_ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        base = (self._joint_ws.data_ptr() + 255) // 256 * 256
+        ptrs = (ctypes.c_void_p * len(frames))(*[f.data_ptr() for f in frames])
+        self.L.burst_process_joint(self._h, ptrs, base, nbytes, self._img_out.data_ptr(), self._total_weights.data_ptr(),
+                                   self._stream())
+        return self.finish()
+
+    # ---- building blocks of stripe-sharded (multi-GPU) bursts: mfsr_burst_align_frame / mfsr_burst_fuse_rows ----
+    def field_dims(self):
+        """((flow_h, flow_w), (mask_h, mask_w)) of the per-frame products."""
+        v = [ctypes.c_int() for _ in range(4)]
+        self.L.burst_field_dims(self._h, *[ctypes.byref(x) for x in v])
+        return (v[1].value, v[0].value), (v[3].value, v[2].value)
+
+    def new_frame_products(self):
+        """(flow [fh, fw, 2] f32, mask [mh, mw, 4] f32) device tensors with dense rows (a row range = one message)."""
+        (fh, fw), (mh, mw) = self.field_dims()
+        return (torch.empty(fh, fw, 2, dtype=torch.float32, device=self.device),
+                torch.empty(mh, mw, 4, dtype=torch.float32, device=self.device))
+
+    def align_frame(self, raw: torch.Tensor, is_reference: bool, flow: torch.Tensor, mask: torch.Tensor):
+        self._check_raw(raw)
+        self.L.burst_align_frame(self._h, raw.data_ptr(), 1 if is_reference else 0, flow.data_ptr(), flow.stride(0) * 4,
+                                 mask.data_ptr(), mask.stride(0) * 4, self._stream())
+
+    def fuse_rows(self, raws, flows, masks, row_begin: int, row_end: int, fresh: bool):
+        n = len(raws)
+        P = ctypes.c_void_p * n
+        self.L.burst_fuse_rows(self._h, n, P(*[r.data_ptr() for r in raws]), P(*[f.data_ptr() for f in flows]),
+                               flows[0].stride(0) * 4, P(*[m.data_ptr() for m in masks]), masks[0].stride(0) * 4,
+                               self._img_out.data_ptr(), self._total_weights.data_ptr(), 1 if fresh else 0, row_begin, row_end,
+                               self._stream())
+
+    def check_flow_bound(self, flow_rows: torch.Tensor, bound: float, flag: torch.Tensor):
+        """flag |= 1 if a vertical flow of these rows exceeds ``bound`` (mfsr_checkFlowBound)."""
+        self.L.checkFlowBound(flow_rows.data_ptr(), flow_rows.stride(0) * 4, flow_rows.shape[1], flow_rows.shape[0], bound,
+                              flag.data_ptr(), self._stream())
+
+    def stripe_plan(self, world: int, rank: int, raw_halo: int = 64) -> "capi.StripePlan":
+        plan = capi.StripePlan()
+        self.L.dist_stripe_plan(ctypes.byref(self.cfg), world, rank, raw_halo, ctypes.byref(plan))
+        return plan
+
     # ---- frames in (pinned) host memory: the library uploads them on its own copy stream (cfg.uploadRing > 0) ----
     def process_host(self, host_frames: Sequence[torch.Tensor], out16_host: Optional[torch.Tensor] = None):
         """Whole burst from HOST frames (pin them: ``t.pin_memory()``) to the u16 HR image in host memory:
@@ -148,21 +202,6 @@ class BurstPipeline:
                                  out16_host.data_ptr(), st)
         return out16_host
 
-    def process_stream(self, frames: Sequence[torch.Tensor], radius: int = 1):
-        """Sliding-window ("temporal area radius", reference multi_frame_sr.cpp:182) use of the burst path:
-        output t fuses frames [t-radius, t+radius] (clipped to the stream) with frame t as the reference.
-        Yields (t, u16 HR image) -- the image is the pipeline's output buffer, valid until the next step.
-        cfg.frames only sizes nothing here: any window length works with one context."""
-        n = len(frames)
-        for t in range(n):
-            lo, hi = max(0, t - radius), min(n - 1, t + radius)
-            self.begin_burst()
-            self.set_reference(frames[t])
-            for k in range(lo, hi + 1):
-                self.add_frame(frames[k], k == t)
-            _, out16 = self.finish(want_float=False, want_u16=True)
-            yield t, out16
-
     def debug_views(self):
         """(flow, mask, kernel_param, tracking) descriptors of the last add_frame."""
         t = [capi.Tex2D() for _ in range(4)]
@@ -174,6 +213,64 @@ class BurstPipeline:
             raise ValueError("raw frame must be a contiguous 16-bit tensor on the pipeline's device")
         if tuple(raw.shape) != (self.cfg.height, self.cfg.width):
             raise ValueError(f"raw frame must be {self.cfg.height}x{self.cfg.width}, got {tuple(raw.shape)}")
+
+
+class FrameStream:
+    """Sliding-window stream (C-ABI ``mfsr_stream_*``; the reference's ``setTemporalAreaRadius``,
+    finalProject/Project/multi_frame_sr.cpp:182): output t fuses frames [t-radius, t+radius] around reference t.  Every
+    frame is uploaded and prepared once.  ``host_frames``: frames are pinned CPU tensors, uploaded by the library's
+    copy stream."""
+
+    def __init__(self, cfg: capi.Config, radius: int = 1, device: Optional[torch.device] = None, host_frames: bool = False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("multi_frame_super_resolution_amd needs a HIP device (MI355X); there is no CPU fallback")
+        self.L = capi.lib()
+        self.cfg = cfg
+        self.radius = radius
+        self.host_frames = host_frames
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        nbytes = self.L.stream_workspace_bytes(ctypes.byref(cfg), radius)
+        if nbytes == 0:
+            raise ValueError("invalid mfsr_config / radius")
+        with torch.cuda.device(self.device):
+            self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            base = (self.workspace.data_ptr() + 255) // 256 * 256
+            self.hr_w, self.hr_h = cfg.width * cfg.scale, cfg.height * cfg.scale
+            self.out16 = torch.empty(self.hr_h, self.hr_w, 3, dtype=torch.int16, device=self.device)
+            h = ctypes.c_void_p()
+            self.L.stream_create(ctypes.byref(h), ctypes.byref(cfg), radius, 1 if host_frames else 0, base, nbytes)
+            self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, frame: torch.Tensor):
+        """Hand over the next frame; returns (t, u16 HR image) once output t is produced (the image is this object's
+        buffer, valid until the next push / drain), else None."""
+        if frame.is_cuda == self.host_frames or not frame.is_contiguous() or tuple(frame.shape) != (self.cfg.height, self.cfg.width):
+            raise ValueError("frame must be a contiguous 16-bit tensor of the configured size, on the "
+                             + ("host" if self.host_frames else "device"))
+        produced = ctypes.c_longlong(-1)
+        self.L.stream_push(self._h, frame.data_ptr(), None, self.out16.data_ptr(), ctypes.byref(produced),
+                           torch.cuda.current_stream().cuda_stream)
+        return (produced.value, self.out16) if produced.value >= 0 else None
+
+    def drain(self):
+        """End of the stream: yields the outstanding (t, u16 HR image) outputs."""
+        while True:
+            produced = ctypes.c_longlong(-1)
+            self.L.stream_drain(self._h, None, self.out16.data_ptr(), ctypes.byref(produced), torch.cuda.current_stream().cuda_stream)
+            if produced.value < 0:
+                return
+            yield produced.value, self.out16
 
 
 def view_as_tensor(t: capi.Tex2D, channels: int, device) -> torch.Tensor:

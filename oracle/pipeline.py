@@ -132,7 +132,8 @@ class OraclePipeline:
             shifts = found
         return shifts
 
-    def add_frame(self, raw, is_reference, img_out, total_weights):
+    def add_frame(self, raw, is_reference, img_out, total_weights, given_shifts=None):
+        """given_shifts: tile shifts [tcy, tcx, 2] from the joint minimiser (process_joint) instead of the tracker's."""
         o, c = self.o, self.c
         o.set_cfa_pattern(self.cfa)
         if is_reference:
@@ -150,7 +151,7 @@ class OraclePipeline:
                 base = (float(res[0]), float(res[1]), float(res[2]))
                 self.prealign = dict(shift=(float(res[0]), float(res[1])), rotation=float(res[2]), angle_index=int(st[0]),
                                      t=(int(st[1]), int(st[2])), level=int(st[3]))
-            shifts = self._track(mov_pyr, base)
+            shifts = self._track(mov_pyr, base) if given_shifts is None else given_shifts
             tcx, tcy = self.tc[-1]
             flow = np.zeros((self.th, self.tw, 2), np.float32)
             o.CreateFlowFieldFromTiles(flow, shifts, _pitch(shifts), tcx, tcy, c.tileSize[c.levels - 1], tcx, tcy,
@@ -193,6 +194,63 @@ class OraclePipeline:
             q = np.zeros((self.hrH, self.hrW, 3), np.uint16)
             o.quantize(out, _pitch(out), q, None, self.hrW, self.hrH, 65535.0)
         return out, q
+
+    @staticmethod
+    def joint_pairs(n, ref):
+        """Pairs (a < b) the joint mode measures: neighbours first, then the reference against every non-neighbour
+        (same order as csrc/pipeline.cpp::joint_pairs)."""
+        pairs = [(k, k + 1) for k in range(n - 1)]
+        for k in range(n):
+            a, b = (k, ref) if k < ref else (ref, k)
+            if b - a >= 2:
+                pairs.append((a, b))
+        return pairs
+
+    def process_joint(self, frames):
+        """Whole burst with the joint shift minimiser (stage C, ShiftMinimizerKernels.cu:81-258) between the tile tracker
+        and the flow field: mirrors mfsr_burst_process_joint.  Returns (float HR image, u16 HR image)."""
+        o, c = self.o, self.c
+        n, ref = len(frames), c.reference
+        n1 = n - 1
+        prods = [self._prepare(f) for f in frames]
+        pairs = self.joint_pairs(n, ref)
+        m = len(pairs)
+        tcx, tcy = self.tc[-1]
+        tiles = tcx * tcy
+        measured = np.zeros((tiles, m, 2), np.float32)
+        for p, (a, b) in enumerate(pairs):
+            self.ref_pyr = prods[a][1]
+            sh = self._track(prods[b][1])                       # [tcy, tcx, 2]
+            measured[:, p, :] = sh.reshape(tiles, 2)            # concatenateShifts (:223): pure data movement
+        A = np.zeros((tiles, n1 * m), np.float32)              # column-major m x n1 per tile (:137)
+        for p, (a, b) in enumerate(pairs):
+            for col in range(a, b):
+                A[0, p + col * m] = 1.0
+        o.copyShiftMatrix(A, tiles, n, m)
+        one = np.zeros((tiles, n1, 2), np.float32)
+        opt = np.zeros((tiles, 2, m), np.float32)
+        info = np.zeros(tiles, np.int32)
+        status = np.zeros(tiles, np.int32)
+        for _ in range(m + 1):
+            o.solveShiftsBatched(A, measured, one, opt, info, tiles, n, m)
+            o.checkForOutliers(measured, opt, A, status, info, tiles, n, m)
+            if (status < 0).all():
+                break
+        self.joint = dict(pairs=pairs, one_to_one=one.copy(), status=status.copy(), dropped=int((A.reshape(tiles, n1, m).sum(1) == 0).sum()))
+        img_out = np.zeros((self.hrH, self.hrW, 3), np.float32)
+        tw = np.zeros_like(img_out)
+        self.set_reference(frames[ref])
+        self.flows, self.masks = [], []
+        for k, f in enumerate(frames):
+            given = None
+            if k != ref:
+                given = np.zeros((tcy, tcx, 2), np.float32)
+                o.getOptimalShifts(given, one, n, tcx, tcy, _pitch(given), ref, k)
+            self.add_frame(f, k == ref, img_out, tw, given_shifts=given)
+            self.flows.append(self.flow)
+            self.masks.append(self.mask)
+        self.img_out, self.tw = img_out, tw
+        return self.finish(img_out, tw)
 
     def process(self, frames):
         """frames: list of HxW uint16 arrays; returns (float HR image, u16 HR image)."""

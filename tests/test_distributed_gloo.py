@@ -54,6 +54,53 @@ class OraclePipe:
         return self.out16
 
 
+class OracleStripePipe(OraclePipe):
+    """Stand-in with the stripe building blocks (align_frame / fuse_rows / finish_rows / stripe_plan) on the oracle."""
+
+    device = torch.device("cpu")
+
+    def new_frame_products(self):
+        o = self.op
+        return torch.full((o.th, o.tw, 2), float("nan")), torch.full((o.hh, o.hw, 4), float("nan"))
+
+    def align_frame(self, raw, is_reference, flow, mask):
+        scratch_a = np.zeros((H * S, W * S, 3), np.float32)
+        scratch_w = np.zeros_like(scratch_a)
+        self.op.add_frame(raw.numpy().view(np.uint16), is_reference, scratch_a, scratch_w)   # alignment (+ an unused fuse)
+        flow.copy_(torch.from_numpy(self.op.flow))
+        mask.copy_(torch.from_numpy(self.op.mask))
+        self.added.append(bool(is_reference))
+
+    def fuse_rows(self, raws, flows, masks, row_begin, row_end, fresh):
+        o = self.op
+        if fresh:
+            self.img_out[row_begin:row_end] = 0
+            self.total_weights[row_begin:row_end] = 0
+        for raw, flow, mask in zip(raws, flows, masks):
+            # the oracle fuses the whole frame; rows outside the stripe see the garbage of rows never received and are dropped
+            a = self.img_out.numpy().copy()
+            w = self.total_weights.numpy().copy()
+            f, m = flow.numpy(), mask.numpy()
+            with np.errstate(all="ignore"):
+                o.o.set_cfa_pattern(o.cfa)
+                o.o.accumulateSuperResFull(raw.numpy().view(np.uint16), a, w, m, o.kparam4, int(o.kparam4.strides[0]), o.tw, o.th,
+                                           f, int(f.strides[0]), o.tw, o.th, o.white, o.black, o.W, o.H, S, int(a.strides[0]),
+                                           int(m.strides[0]))
+            self.img_out[row_begin:row_end] = torch.from_numpy(a[row_begin:row_end])
+            self.total_weights[row_begin:row_end] = torch.from_numpy(w[row_begin:row_end])
+
+    def check_flow_bound(self, flow_rows, bound, flag):
+        if not bool((flow_rows[..., 1].abs() <= bound).all()):
+            flag |= 1
+
+    def stripe_plan(self, world, rank, raw_halo=64):
+        import ctypes
+        from multi_frame_super_resolution_amd import capi
+        plan = capi.StripePlan()
+        assert capi.lib().raw["mfsr_dist_stripe_plan"](ctypes.byref(self.cfg), world, rank, raw_halo, ctypes.byref(plan)) == 0
+        return plan
+
+
 def _cfg():
     import ctypes
     from multi_frame_super_resolution_amd import capi
@@ -80,13 +127,17 @@ def _worker(rank, world, port, mode, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from multi_frame_super_resolution_amd import distributed as mdist
-        pipe = OraclePipe(_cfg())
+        pipe = OracleStripePipe(_cfg()) if mode == "stripes" else OraclePipe(_cfg())
         frames = _frames()
         # a rank keeps only its shard + the reference resident
         mine = mdist.frames_of_rank(N, rank, world)
         local = {k: frames[k] for k in mine}
         local[0] = frames[0]
-        out = mdist.process_burst(pipe, local, mode=mode, n_frames=N)
+        if mode == "stripes":
+            out, flag = mdist.process_burst_stripes(pipe, local, n_frames=N, raw_halo=8)
+            assert int(flag.item()) == 0
+        else:
+            out = mdist.process_burst(pipe, local, mode=mode, n_frames=N)
         added = torch.tensor([len(pipe.added), sum(pipe.added)], dtype=torch.int64)
         dist.all_reduce(added)
         if rank == 0:
@@ -105,7 +156,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode", ["reduce", "reduce_scatter", "auto"])
+@pytest.mark.parametrize("mode", ["reduce", "reduce_scatter", "auto", "stripes"])
 def test_two_ranks_equal_single_process(mode):
     from multi_frame_super_resolution_amd import distributed as mdist
     # single process reference
@@ -124,6 +175,11 @@ def test_two_ranks_equal_single_process(mode):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert added == [N, 1]          # every frame exactly once, the reference exactly once
+    if mode == "stripes":
+        # stripes fuse every frame in frame order on each rank's rows: the single-process summation order, bit for bit
+        # (the rows a rank never received stay NaN in its buffers, so a read outside the plan's ranges would show)
+        assert np.array_equal(got, single)
+        return
     d = np.abs(got.astype(np.int64) - single.astype(np.int64))
     # fp32 sum order differs between the sharded and the sequential accumulation
     assert d.max() <= 2 and np.mean(d > 0) < 0.05

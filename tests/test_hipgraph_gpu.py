@@ -41,3 +41,53 @@ def test_burst_captures_into_one_hipgraph():
         assert torch.equal(g16, eager[k]), f"burst {k}: graph replay differs from the eager launch sequence"
     pipe.close()
     gpipe.close()
+
+
+def test_config4_8k_frames_graph_replay_and_host_ring():
+    """BASELINE configs[4] at its own frame size (7680x4320 RGGB, x2; 8 frames = one GPU's share of the 64-frame burst at 8
+    GPUs): (a) the burst captured into one hipGraph replays bit-identically on new frame data; (b) the same burst with its
+    frames in pinned HOST memory, uploaded by the library's copy stream through a 4-slot device ring ahead of the compute
+    (mfsr_burst_*_host: the double-buffered H2D of configs[4]), and the u16 result copied back, is bit-identical to the
+    HBM-resident burst; (c) a moved frame's flow locks at this size."""
+    import torch
+    from multi_frame_super_resolution_amd import synth
+    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, default_config, view_as_tensor
+    dev = torch.device("cuda:0")
+    W, H, N = 7680, 4320, 8
+    cfg = default_config(W, H, N, scale=2)
+    cfg.uploadRing = 4
+    # two bursts of one scene: frames 0..7 and a second draw of shifts / noise
+    a, shifts, _ = synth.make_burst(W, H, N, seed=1234 + 4, device=dev)
+    b, _, _ = synth.make_burst(W, H, N, seed=1234 + 4, device=dev, shift_seed=99)
+    pipe = BurstPipeline(cfg, dev)
+    eager = []
+    for frames in (a, b):
+        _, o16 = pipe.process(frames)
+        eager.append(o16.clone())
+    fl = view_as_tensor(pipe.debug_views()[0], 2, dev)      # flow of the last frame of burst b
+    torch.cuda.synchronize()
+    static = [f.clone() for f in a]
+    pipe.process(static)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        _, g16 = pipe.process(static)
+    for k, frames in enumerate((a, b)):
+        for dst, src in zip(static, frames):
+            dst.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g16, eager[k]), f"8K burst {k}: graph replay differs"
+    del graph
+    # (b) host frames through the library's upload ring
+    host = [f.cpu().pin_memory() for f in a]
+    for rep in range(2):
+        got = pipe.process_host(host)
+        torch.cuda.synchronize()
+        assert torch.equal(got, eager[0].cpu()), f"host-ring burst {rep} differs from the resident burst"
+    # (c) the alignment locked at 8K (flow of the last frame of the first burst: recompute eagerly)
+    pipe.process(a)
+    fl = view_as_tensor(pipe.debug_views()[0], 2, dev)
+    c = fl[fl.shape[0] // 4: -fl.shape[0] // 4, fl.shape[1] // 4: -fl.shape[1] // 4].reshape(-1, 2)
+    np.testing.assert_allclose(c.median(0).values.cpu().numpy(), -shifts[N - 1].cpu().numpy(), atol=0.15)
+    pipe.close()

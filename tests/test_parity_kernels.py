@@ -651,6 +651,18 @@ def test_minimizeShifts_driver(orc, hip):
     assert nr.value == rounds
     assert_bitexact(one, tone.cpu().numpy(), "minimizeShifts oneToOne")
     assert (tstat.cpu().numpy() == -1).all()
+    # the same loop inside one launch, no host round trips (what the burst pipeline's joint mode uses)
+    fA, fms = torch.from_numpy(A0).to(dev), torch.from_numpy(meas).to(dev)
+    fone, fopt = torch.zeros_like(tone), torch.zeros_like(topt)
+    finfo, fstat = torch.full_like(tinfo, 5), torch.full_like(tstat, 5)
+    hip.L.minimizeShiftsFused(fA.data_ptr(), fms.data_ptr(), fone.data_ptr(), fopt.data_ptr(), fstat.data_ptr(), finfo.data_ptr(),
+                              tiles, n_img, m, None)
+    torch.cuda.synchronize()
+    assert_bitexact(one, fone.cpu().numpy(), "minimizeShiftsFused oneToOne")
+    assert_bitexact(opt, fopt.cpu().numpy(), "minimizeShiftsFused optimShiftsT")
+    assert_bitexact(A, fA.cpu().numpy(), "minimizeShiftsFused shiftMatrix")
+    assert_bitexact(ms, fms.cpu().numpy(), "minimizeShiftsFused measuredShifts")
+    assert (fstat.cpu().numpy() == -1).all() and (finfo.cpu().numpy() == info).all()
 
 
 def test_shift_glue_kernels(orc, hip):
@@ -892,6 +904,37 @@ def test_ComputeRobustnessMask(orc, hip):
     np.testing.assert_allclose(h, o, atol=1e-6, rtol=1e-6)
     assert (h[0] == 0).all() and (h[:, -1] == 0).all()  # ring untouched
     assert h[..., :3].max() > 0.5 and h[..., :3].min() == 0.0
+
+
+@pytest.mark.parametrize("uv_scale", [1, 2])
+def test_robustnessMaskFused(orc, hip, uv_scale):
+    """The MI355X robustness kernel (LDS reference tile, hardware sqrt / rcp / exp, zero ring folded in) against the
+    oracle's ComputeRobustnessMask: mask within 2e-6, the rounded moved-patch shifts identical (they are taken with the
+    straight kernel's arithmetic), also with the flow field at twice the image resolution (monochrome pipeline)."""
+    H, W = 75, 141          # partial tiles on both axes
+    r = rng(61)
+    ref = r.random((H, W, 3), dtype=np.float32)
+    mov = np.clip(ref + r.normal(0, 0.02, ref.shape).astype(np.float32), 0, 1).astype(np.float32)
+    mov[5:9, 5:9] += 0.5
+    uv = r.uniform(-5, 5, (H * uv_scale, W * uv_scale, 2)).astype(np.float32)
+    mo = np.zeros((H, W, 4), np.float32)
+    orc.call("ComputeRobustnessMask", ref, mov, mo, Tex(uv), W, H, pitch_of(ref), pitch_of(mo), 1e-4, 1e-6, 0.8)
+    mh = np.full((H, W, 4), 99.0, np.float32)
+    hip.call("robustnessMaskFused", ref, mov, mh, Tex(uv), W, H, pitch_of(ref), pitch_of(mh), 1e-4, 1e-6, 0.8)
+    assert (mh[0] == 0).all() and (mh[-1] == 0).all() and (mh[:, 0] == 0).all() and (mh[:, -1] == 0).all()
+    # M decides s = 1.5 / 0 at the threshold: compare where both sides are on the same side of it (1-ulp sqrt)
+    same = (mo[..., 3] > 0.8) == (mh[..., 3] > 0.8)
+    assert same.mean() > 0.999
+    d = np.abs(mh - mo) * same[..., None]
+    worst = np.unravel_index(np.argsort(d.reshape(-1))[-3:], d.shape)
+    for y, x, c in zip(*worst):
+        print(f"worst |d| {d[y, x, c]:.2e} at ({y},{x}) ch {c}: hip {mh[y, x]} oracle {mo[y, x]} ref patch std "
+              f"{ref[y - 1:y + 2, x - 1:x + 2].std(axis=(0, 1))}")
+    print("fraction of mask samples off by more than 2e-6:", float((d[..., :3] > 2e-6).mean()))
+    # hardware sqrt / rcp / exp (1 ulp each) through exp(-d^2 / sigma^2): a few 1e-6 where the exponent is large
+    np.testing.assert_allclose(mh[same], mo[same], atol=1e-5, rtol=2e-6)
+    assert float((d[..., :3] > 2e-6).mean()) < 5e-3
+    assert mh[..., :3].max() > 0.5 and (mh[..., :3] == 0).any()
 
 
 # ---------------------------------------------------------------- H / I / glue

@@ -294,31 +294,50 @@ def test_begin_burst_equals_zeroed_accumulators(scale, mono):
     pipe.close()
 
 
-@pytest.mark.parametrize("scale", [1, 2])
-def test_sliding_window_stream_equals_bursts(scale):
-    """process_stream (sliding window over a frame stream, also the x1
-    denoise-merge scale) gives, for every t, exactly the burst of its window with frame t as reference."""
+@pytest.mark.parametrize("scale,radius,host", [(1, 1, False), (2, 1, True), (2, 2, False)])
+def test_frame_stream_matches_oracle_per_window(scale, radius, host):
+    """mfsr_stream_* (sliding window over a frame stream, also the x1 denoise-merge scale):
+    every output t is compared with the ORACLE burst of its window (frames [t-R, t+R] clipped, reference t), and is
+    bit-identical to the HIP burst of the same window -- although the stream uploads and prepares each frame once and
+    keeps its products in a ring.  One window also goes through the flip-set classification."""
     import torch
     from multi_frame_super_resolution_amd import synth
-    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, default_config
+    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, FrameStream, default_config
+    from oracle.pipeline import OraclePipeline
     dev = torch.device("cuda:0")
-    W, H, N, R = 256, 192, 5, 1
-    frames, _, _ = synth.make_burst(W, H, N, scale=scale, seed=23, device=dev, max_shift=2.0)
+    W, H, N, R = 256, 192, 6, radius
+    frames, _, _ = synth.make_burst(W, H, N, scale=scale, seed=23, max_shift=2.0)
     cfg = default_config(W, H, 2 * R + 1, scale=scale)
-    pipe = BurstPipeline(cfg, dev)
-    stream = {t: o.clone() for t, o in pipe.process_stream(frames, radius=R)}
-    assert sorted(stream) == list(range(N))
-    ref = BurstPipeline(cfg, dev)
+    st = FrameStream(cfg, R, dev, host_frames=host)
+    outs = {}
+    feed = [f.pin_memory() for f in frames] if host else [f.to(dev) for f in frames]
+    for f in feed:
+        r = st.push(f)
+        if r is not None:
+            outs[r[0]] = r[1].clone()
+    for t, o in st.drain():
+        outs[t] = o.clone()
+    torch.cuda.synchronize()
+    st.close()
+    assert sorted(outs) == list(range(N))
     for t in range(N):
         lo, hi = max(0, t - R), min(N - 1, t + R)
         window = frames[lo:hi + 1]
-        ref.cfg.reference = t - lo
-        _, o16 = ref.process(window)
-        assert torch.equal(o16, stream[t]), f"t={t}"
-    # the middle outputs really fuse three different frames
-    assert not torch.equal(stream[1], stream[2])
-    pipe.close()
-    ref.close()
+        wcfg = default_config(W, H, len(window), scale=scale)
+        wcfg.reference = t - lo
+        ref = BurstPipeline(wcfg, dev)
+        _, o16 = ref.process([f.to(dev) for f in window])
+        assert torch.equal(o16, outs[t]), f"t={t}"
+        ref.close()
+        _, oq = OraclePipeline(wcfg).process([f.numpy().view(np.uint16) for f in window])
+        d = np.abs(outs[t].cpu().numpy().view(np.uint16).astype(np.int64) - oq.astype(np.int64))
+        d8 = d / 257.0
+        assert np.mean(d8 > 1.0) <= 1e-3, (t, float(np.mean(d8 > 1.0)))
+        if t == 2:
+            h = run_hip(wcfg, window)
+            o = run_oracle(wcfg, window)
+            assert_parity(classify(wcfg, h, o), f"stream window t={t} scale {scale}")
+    assert not torch.equal(outs[1], outs[2])
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -471,3 +490,45 @@ def test_host_frame_burst_equals_device_frame_burst(ring, pair, async_fuse):
             assert torch.equal(got, want), (ref, rep)
             got.zero_()
         pipe.close()
+
+
+@pytest.mark.parametrize("ref_index", [0, 2])
+def test_joint_minimiser_burst_matches_oracle(ref_index):
+    """Stage C in the pipeline (mfsr_burst_process_joint): neighbouring pairs measured besides the (reference, k) pairs,
+    per-tile least squares with outlier rejection inside one launch (mfsr_minimizeShiftsFused), getOptimalShifts feeding
+    the flow field -- against the oracle's process_joint (same pairs, host-driven solve / checkForOutliers loop)."""
+    import torch
+    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, view_as_tensor
+    from multi_frame_super_resolution_amd.synth import make_burst
+    from oracle.pipeline import OraclePipeline
+    dev = torch.device("cuda:0")
+    W, H, N = 320, 256, 5
+    frames, shifts, gt = make_burst(W, H, N, scale=2, mono=False, seed=1234 + 7, max_shift=3.0)
+    cfg = _cfg(W, H, N, 2, False, 1)
+    cfg.reference = ref_index
+    nf = [f.numpy().view(np.uint16) for f in frames]
+    op = OraclePipeline(cfg)
+    o_out, o_q = op.process_joint(nf)
+    pipe = BurstPipeline(cfg, dev)
+    h_out, h_q = pipe.process_joint([f.to(dev) for f in frames])
+    torch.cuda.synchronize()
+    flow_t, mask_t, _, _ = pipe.debug_views()
+    h = dict(out=h_out.cpu().numpy(), out16=h_q.cpu().numpy().view(np.uint16), tw=pipe.total_weights.cpu().numpy(),
+             flows=[None] * (N - 1) + [view_as_tensor(flow_t, 2, dev).cpu().numpy()],
+             masks=[None] * (N - 1) + [view_as_tensor(mask_t, 4, dev).cpu().numpy()])
+    # the tile shifts out of the minimiser are bit-identical (tracker and solve are); the last frame's flow agrees to LK rounding
+    last = N - 1 if ref_index != N - 1 else N - 2
+    assert last == N - 1
+    dflow = np.abs(h["flows"][-1] - op.flows[-1])
+    assert np.mean(dflow > 1e-3) < 1e-3
+    d8 = np.abs(np.round(np.clip(h["out"], 0, 1) * 255) - np.round(np.clip(o_out, 0, 1) * 255))
+    psnr = _psnr(h["out"], o_out)
+    print(f"joint burst ref={ref_index}: PSNR vs oracle {psnr:.1f} dB, 8-bit >1 LSB {float((d8 > 1).mean()):.2e}, "
+          f"oracle dropped {op.joint['dropped']} measurements")
+    assert psnr >= 70.0 and float((d8 > 1).mean()) <= 1e-3
+    # and the joint result is a sensible super-resolution: close to the plain burst's
+    plain = BurstPipeline(cfg, dev)
+    p_out, _ = plain.process([f.to(dev) for f in frames])
+    assert _psnr(p_out.cpu().numpy(), h["out"]) > 35.0
+    pipe.close()
+    plain.close()
