@@ -249,6 +249,12 @@ int mfsr_gaussin_filter_1D(float sigma, float* taps);
 int mfsr_sharpenImg2(const uint8_t* img, uint8_t* result, int rows, int cols, int ch, int stepIn, int stepOut,
                      mfsr_stream_t stream);
 
+/* sharpenImg, test_opencv/main.cpp:525-534: unsharp mask (sigma 1, threshold 5, amount 1) on DEVICE u8 interleaved
+ * images; tmp: rows*cols*ch device bytes.  The Gaussian blur is third-party there (cv::GaussianBlur): restated from its
+ * published definition, parity unpinned (oracle/glue.c). */
+int mfsr_sharpenImg(const uint8_t* img, uint8_t* result, uint8_t* tmp, int rows, int cols, int ch, int stepIn, int stepOut,
+                    mfsr_stream_t stream);
+
 /* ---- glue stages between the reference kernels (the build's own; the
  *      reference has no host for this path -- DESIGN.md "Pipeline glue") ---- */
 int mfsr_rgbToGray(const mfsr_float3* in, int inPitch, float* out, int outPitch, int width, int height,
@@ -530,6 +536,22 @@ int mfsr_stream_reset(mfsr_stream* s);
 size_t mfsr_burst_joint_workspace_bytes(const mfsr_config* cfg);
 int mfsr_burst_process_joint(mfsr_burst* b, const uint16_t* const* frames, void* jointWorkspace, size_t jointBytes,
                              mfsr_float3* imgOut, mfsr_float3* totalWeights, mfsr_stream_t stream);
+
+/* ---- frame-source plug-in: the pull model of the reference's cv::superres::FrameSource subclass
+ * (MultiFrameSource_CUDA, finalProject/Project/multi_frame_sr.cpp:18-49: nextFrame copies the next device-resident frame
+ * into the caller's buffer and leaves it empty when exhausted; reset rewinds).  Same ownership: the library owns the
+ * destination (a slot of the burst's upload ring, cfg.uploadRing >= 3), the callee fills it. */
+typedef struct {
+    /* copy the next frame (dense u16, width x height) into dst (DEVICE memory) with work enqueued on `stream`;
+     * return 1 = delivered, 0 = source exhausted, < 0 = error (returned to the caller of process_source) */
+    int (*next_frame)(void* user, uint16_t* dst, mfsr_stream_t stream);
+    void (*reset)(void* user);   /* may be NULL */
+    void* user;
+} mfsr_frame_source;
+/* reset, then pull up to cfg.frames frames (the first one is the reference: cfg.reference must be 0), fuse them and
+ * finish into outImg / out16 (either may be NULL); *framesUsed = frames delivered.  imgOut / totalWeights: accumulators. */
+int mfsr_burst_process_source(mfsr_burst* b, const mfsr_frame_source* src, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                              mfsr_float3* outImg, uint16_t* out16, int* framesUsed, mfsr_stream_t stream);
 
 /* HIP-event timing of the warp+fuse (accumulate) launches made by add_frame on
  * the caller's stream: timing(b,1) starts a series, timing_read synchronises with

@@ -196,7 +196,11 @@ __device__ __forceinline__ void tap_weights13(float kx, float ky, float kz, floa
 //    four values instead of one select per tap;
 //  * exponents from pre-scaled sums: 2 adds per weight instead of mul+2 adds+mul.
 // ~245 VALU instructions per pixel instead of ~330; sums re-associated again (fma), same tolerance.
-template <int K, int CFA, typename MaskF>
+// PARITY = true (the LDS tile kernel): mval(jt, cell, e) returns the certainty of the colour at CFA position e =
+// (y parity << 1) | x parity of mask cell `cell` on tap row jt's mask row -- the certainty texels are staged in LDS in
+// CFA-position order, so "which channel does this site see" is an LDS ADDRESS (a few integer ops per pixel) instead of
+// three v_bitop3 selects per tap row and cell.
+template <int K, int CFA, bool PARITY = false, typename MaskF>
 __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float kx, float ky, float kz,
                                              const uint16_t* __restrict__ raw, int dimX, MaskF mval,
                                              const StripLevels& lv, float* accP, float* accW)
@@ -247,12 +251,25 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
         if (jt == 1) mya = mY13;
         if (jt == 3) mya = ~mY13;
         float Ee[2], Eo[2];  // certainty of the colour on even / odd site columns (relative to x0), per cell
+        if constexpr (PARITY) {
+            // CFA position of an even site column on this tap row: y parity Q (rows 0, 4), ~Q (row 2), Q ^ by (row 1),
+            // ~(Q ^ by) (row 3); x parity P.  Odd site columns: x parity flipped.
+            const int eQ = ((y0 & 1) << 1) | (x0 & 1);
+            const int by2 = (qy & 1) << 1;
+            const int e = (jt == 0 || jt == 4) ? eQ : (jt == 2 ? (eQ ^ 2) : (jt == 1 ? (eQ ^ by2) : (eQ ^ 2 ^ by2)));
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-            float m[3];
+            for (int c = 0; c < 2; c++) {
+                Ee[c] = mval(jt, cellLo + c, e);
+                Eo[c] = mval(jt, cellLo + c, e ^ 1);
+            }
+        } else {
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) m[ch] = mval(jt, cellLo + c, ch);
-            resolve_certainty<CFA>(mya, mP, m, Ee[c], Eo[c]);
+            for (int c = 0; c < 2; c++) {
+                float m[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) m[ch] = mval(jt, cellLo + c, ch);
+                resolve_certainty<CFA>(mya, mP, m, Ee[c], Eo[c]);
+            }
         }
         // site column 0: tap 0, tap 1 if bx == 0
         C[jt][0] = cidx(0) == cidx(1) ? (W_(jt, 0) + WL(jt, 1)) * Ee[cidx(0)]
@@ -581,7 +598,10 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
             for (int n = 0; n < NF; n++) {
                 sF[n][r][c] = row_ptr((const float2*)fr.f[n].shifts.ptr, fr.f[n].shifts.pitch, fy)[fx];
                 const float4 m = row_ptr(fr.f[n].mask, strideMask, clampi(gy, 0, mh - 1))[clampi(gx, 0, mw - 1)];
-                sM[n][r][c] = make_float4(sane(m.x), sane(m.y), sane(m.z), 0.0f);
+                // stored by CFA position (y parity << 1 | x parity), not by channel: strip_pixel<PARITY> indexes it
+                const float mc[3] = {sane(m.x), sane(m.y), sane(m.z)};
+                sM[n][r][c] = make_float4(mc[Cfa<CFA>::col(0, 0)], mc[Cfa<CFA>::col(0, 1)], mc[Cfa<CFA>::col(1, 0)],
+                                          mc[Cfa<CFA>::col(1, 1)]);
             }
         }
         {
@@ -718,15 +738,15 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
 #pragma unroll
             for (int k = 0; k < 4; k++) asm volatile("" : "+v"(kxa[k]), "+v"(kya[k]), "+v"(kza[k]));
             // certainty: LDS row of the mask row that tap row jt reads = ((ly + jt - 2) >> 2) + 1; column lx + cell
-            auto mval = [&](int jt, int cell, int ch) {
+            auto mval = [&](int jt, int cell, int e) {
                 const int mr = ((ly + jt - 2) >> 2) + 1;
                 const float* p = (const float*)&sM[n][mr][lx + cell];
-                return p[ch];
+                return p[e];
             };
-            strip_pixel<0, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
-            strip_pixel<1, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
-            strip_pixel<2, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
-            strip_pixel<3, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
+            strip_pixel<0, CFA, true>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
+            strip_pixel<1, CFA, true>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
+            strip_pixel<2, CFA, true>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
+            strip_pixel<3, CFA, true>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
         }
     }
     float* myP = (float*)&sAcc[ly][0][0] + lx * 12;  // this lane's 4 pixels x 3 channels inside the staged segment
@@ -767,7 +787,11 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const size_t off = (size_t)(j * 64 + lx) * 16;
-        if (segByte + off + 16 <= rowBytes) {
+        // the 16-pixel side margins of the row belong to k_accumulateMargin, which may run concurrently on the margin
+        // stream: their (unchanged) chunks are not written back.  A fresh launch defines them (zero) instead.
+        const size_t g = segByte + off;
+        const bool sideMargin = g < (size_t)STRIP_MARGIN * 12 || g + 16 > rowBytes - (size_t)STRIP_MARGIN * 12;
+        if (g + 16 <= rowBytes && (fresh || !sideMargin)) {
             *(float4*)(gP + off) = sAcc[ly][0][j * 64 + lx];
             *(float4*)(gW + off) = sAcc[ly][1][j * 64 + lx];
         }
@@ -1077,7 +1101,9 @@ __global__ void __launch_bounds__(256, 3)
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const size_t off = (size_t)(j * 64 + lx) * 16;
-        if (segByte + off + 16 <= rowBytes) {
+        const size_t g = segByte + off;  // side-margin chunks: see k_accumulate2xTile
+        const bool sideMargin = g < (size_t)STRIP_MARGIN * 12 || g + 16 > rowBytes - (size_t)STRIP_MARGIN * 12;
+        if (g + 16 <= rowBytes && (fresh || !sideMargin)) {
             *(float4*)(gP + off) = sAcc[r][0][h * 192 + j * 64 + lx];
             *(float4*)(gW + off) = sAcc[r][1][h * 192 + j * 64 + lx];
         }
@@ -1141,6 +1167,33 @@ int zero_margin_bands(mfsr_float3* imgOut, mfsr_float3* totalWeights, int hrH, i
     return 0;
 }
 
+// The margin kernel (one thread per pixel of the 16-pixel frame margin, the straight per-pixel arithmetic) is small and
+// latency-bound (5.6 K waves, 25 us per 4K frame) while the tile kernel saturates the VALUs: the two touch disjoint
+// accumulator bytes (the tile kernel does not write the side-margin chunks back), so the margin launches of a call run
+// on a side stream, forked after the tile launch's predecessors and joined before the call returns -- they fill the
+// tile kernel's stalls instead of adding 2 x 25 us per pair.  The first launch of a burst ("fresh": the tile kernel
+// defines the margins' zeroes) keeps the serial order.  MFSR_MARGIN_OVERLAP=0 restores it everywhere (A/B).
+int g_margin_overlap = 0;  // measured: no gain (8.79 vs 8.88 ms per burst, profiles/r02_ab_margin_overlap.txt): off by default
+struct MarginStream {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+MarginStream* margin_stream()
+{
+    static thread_local MarginStream ms[16];  // per host thread: contexts on different threads never share the fork/join events
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    MarginStream& m = ms[dev];
+    if (m.device != dev) {
+        if (hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&m.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&m.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        m.device = dev;
+    }
+    return &m;
+}
+
 void read_env_once()
 {
     static const bool env_read = [] {
@@ -1148,6 +1201,8 @@ void read_env_once()
         if (e && e[0] >= '0' && e[0] <= '1') g_strip_use_tile = e[0] - '0';
         const char* x = getenv("MFSR_XCD_REMAP");
         if (x && (x[0] == '0' || x[0] == '1')) g_strip_xcd_remap = x[0] - '0';
+        const char* mo = getenv("MFSR_MARGIN_OVERLAP");
+        if (mo && (mo[0] == '0' || mo[0] == '1')) g_margin_overlap = mo[0] - '0';
         return true;
     }();
     (void)env_read;
@@ -1209,12 +1264,20 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
             if (hipMemsetAsync((char*)totalWeights + off, 0, bytes, st) != hipSuccess) return -1;
         }
     }
+    // margin launches: on the side stream (forked here, joined after the last one) when a tile kernel leads the call
+    MarginStream* msx = (g_margin_overlap && tileFirst && !tileFresh) ? margin_stream() : nullptr;
+    if (msx && (hipEventRecord(msx->fork, st) != hipSuccess || hipStreamWaitEvent(msx->stream, msx->fork, 0) != hipSuccess)) msx = nullptr;
+    const hipStream_t mst = msx ? msx->stream : st;
     auto launch_margin = [&](int n) {
         const int M = STRIP_MARGIN;
         const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
-        hipLaunchKernelGGL(k_accumulateMargin, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, st, dataIn[n], pI, pT,
+        hipLaunchKernelGGL(k_accumulateMargin, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, mst, dataIn[n], pI, pT,
                            (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp, 2,
                            rowBegin, rowEnd);
+        if (msx && n == nFrames - 1) {
+            (void)hipEventRecord(msx->join, msx->stream);
+            (void)hipStreamWaitEvent(st, msx->join, 0);
+        }
     };
 #define STRIP_CASE(a, b, c, d)                                                                                         \
     case pack_cfa(a, b, c, d):                                                                                         \
@@ -1308,12 +1371,19 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
     if (fresh) {  // the top and bottom margin bands are the only rows the tile kernel does not write
         if (zero_margin_bands(imgOut, totalWeights, hrH, strideOut, rowBegin, rowEnd, st) != 0) return -1;
     }
+    MarginStream* msx = (g_margin_overlap && !fresh) ? margin_stream() : nullptr;
+    if (msx && (hipEventRecord(msx->fork, st) != hipSuccess || hipStreamWaitEvent(msx->stream, msx->fork, 0) != hipSuccess)) msx = nullptr;
+    const hipStream_t mst = msx ? msx->stream : st;
     auto launch_margin = [&](int n) {
         const int M = STRIP_MARGIN;
         const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
-        hipLaunchKernelGGL(k_accumulateMargin, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, st, dataIn[n], pI, pT,
+        hipLaunchKernelGGL(k_accumulateMargin, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, mst, dataIn[n], pI, pT,
                            (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp, 4,
                            rowBegin, rowEnd);
+        if (msx && n == nFrames - 1) {
+            (void)hipEventRecord(msx->join, msx->stream);
+            (void)hipStreamWaitEvent(st, msx->join, 0);
+        }
     };
 #define X4_CASE(a, b, c, d)                                                                                            \
     case pack_cfa(a, b, c, d):                                                                                         \

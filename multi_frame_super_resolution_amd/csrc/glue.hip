@@ -36,6 +36,71 @@ extern "C" int mfsr_device_count(void)
     return n;
 }
 
+// ---- sharpenImg (test_opencv/main.cpp:525-534): unsharp mask on device u8 ----------------------------------------------
+// sigma = 1, threshold = 5, amount = 1.  cv::GaussianBlur is third-party (its 8-bit fixed-point path is not reproduced):
+// 7 taps exp(-x^2/2) normalised, BORDER_REFLECT_101, separable, each pass rounded to 8 bit -- see oracle/glue.c.
+struct SharpTaps {
+    float t[7];
+};
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+__device__ __forceinline__ int sat_u8_rne(float v)
+{
+    const float r = rintf(v);  // cvRound
+    return (int)fminf(fmaxf(r, 0.0f), 255.0f);
+}
+__global__ void __launch_bounds__(256) k_sharpenBlurH(const uint8_t* __restrict__ img, uint8_t* __restrict__ tmp, int rows, int cols,
+                                                     int ch, int stepIn, SharpTaps taps)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (j >= cols * ch) return;
+    const int x = j / ch, c = j - x * ch;
+    float a = 0;
+#pragma unroll
+    for (int k = -3; k <= 3; k++) a += taps.t[k + 3] * (float)img[(size_t)y * stepIn + (size_t)reflect101(x + k, cols) * ch + c];
+    tmp[(size_t)y * cols * ch + j] = (uint8_t)sat_u8_rne(a);
+}
+__global__ void __launch_bounds__(256) k_sharpenFinish(const uint8_t* __restrict__ img, const uint8_t* __restrict__ tmp,
+                                                      uint8_t* __restrict__ result, int rows, int cols, int ch, int stepIn,
+                                                      int stepOut, SharpTaps taps)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (j >= cols * ch) return;
+    float a = 0;
+#pragma unroll
+    for (int k = -3; k <= 3; k++) a += taps.t[k + 3] * (float)tmp[(size_t)reflect101(y + k, rows) * cols * ch + j];
+    const int blurred = sat_u8_rne(a);
+    const int src = img[(size_t)y * stepIn + j];
+    const int diff = max(src - blurred, 0);  // uchar subtraction saturates at 0 (:530)
+    const int sharp = min(max(2 * src - blurred, 0), 255);
+    result[(size_t)y * stepOut + j] = (uint8_t)(diff < 5 ? src : sharp);
+}
+
+extern "C" int mfsr_sharpenImg(const uint8_t* img, uint8_t* result, uint8_t* tmp, int rows, int cols, int ch, int stepIn, int stepOut,
+                               mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(img && result && tmp && rows > 0 && cols > 0 && ch > 0 && stepIn >= cols * ch && stepOut >= cols * ch);
+    MFSR_REQUIRE(rows <= 65535);
+    SharpTaps taps;
+    float sum = 0;
+    for (int i = 0; i < 7; i++) {
+        taps.t[i] = expf(-(float)((i - 3) * (i - 3)) / 2.0f);
+        sum += taps.t[i];
+    }
+    for (int i = 0; i < 7; i++) taps.t[i] /= sum;
+    dim3 grid(mfsr_cdiv((long long)cols * ch, 256), rows);
+    hipLaunchKernelGGL(k_sharpenBlurH, grid, dim3(256), 0, mfsr_s(stream), img, tmp, rows, cols, ch, stepIn, taps);
+    hipLaunchKernelGGL(k_sharpenFinish, grid, dim3(256), 0, mfsr_s(stream), img, (const uint8_t*)tmp, result, rows, cols, ch, stepIn,
+                       stepOut, taps);
+    return mfsr_launch_status("sharpenImg");
+}
+
 // ---- J1: gaussin_filter_1D (test_opencv/main.cpp:370-391), host ------------------
 extern "C" int mfsr_gaussin_filter_1D(float sigma, float* taps)
 {

@@ -1082,6 +1082,50 @@ extern "C" int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, 
     return MFSR_OK;
 }
 
+// ---- frame-source plug-in (pull model of multi_frame_sr.cpp:18-49) ------------------------------------------------------
+extern "C" int mfsr_burst_process_source(mfsr_burst* b, const mfsr_frame_source* src, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                                         mfsr_float3* outImg, uint16_t* out16, int* framesUsed, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && src && src->next_frame && imgOut && totalWeights && (outImg || out16));
+    MFSR_REQUIRE(b->copyStream != nullptr);  // cfg.uploadRing >= 3: the ring slots are the buffers the source fills
+    MFSR_REQUIRE(b->cfg.reference == 0);
+    if (framesUsed) *framesUsed = 0;
+    if (src->reset) src->reset(src->user);
+    TRY(mfsr_burst_begin(b, imgOut, totalWeights, stream));
+    int n = 0;
+    for (; n < b->cfg.frames; n++) {
+        // frame 0 goes to a reference slot (it is read again by every later set of reference products), the others
+        // through the ring; a slot is handed out once its last consumer has been enqueued
+        int us;
+        uint16_t* dst;
+        if (n == 0) {
+            const int i = b->refCounter++ & 1;
+            us = b->cfg.uploadRing + i;
+            dst = b->L.refRaw[i];
+            TRY(flush_pending(b, stream, false));
+        } else {
+            us = b->upCounter++ % b->cfg.uploadRing;
+            dst = b->L.rawRing[us];
+        }
+        if (b->freeRecorded[us]) {
+            MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evFree[us], 0));
+            b->freeRecorded[us] = false;
+        }
+        const int got = src->next_frame(src->user, dst, stream);
+        if (got < 0) return got;
+        if (got == 0) break;  // exhausted (the reference leaves the output array empty, :42)
+        if (n == 0) {
+            b->refHost = nullptr;
+            b->refDev = dst;
+            TRY(mfsr_burst_set_reference(b, dst, stream));
+        }
+        TRY(mfsr_burst_add_frame(b, dst, n == 0, imgOut, totalWeights, stream));
+    }
+    if (framesUsed) *framesUsed = n;
+    if (n == 0) return MFSR_E_INVALID;  // an empty source has no reference frame
+    return mfsr_burst_finish(b, imgOut, totalWeights, outImg, out16, stream);
+}
+
 extern "C" int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2d* mask, mfsr_tex2d* kernelParam,
                                       mfsr_tex2d* tracking)
 {

@@ -74,6 +74,54 @@ void orc_sharpenImg2(const uint8_t* img, uint8_t* result, int rows, int cols, in
     }
 }
 
+/* sharpenImg, test_opencv/main.cpp:525-534: "unsharp mask" on an 8-bit interleaved image, sigma = 1, threshold = 5,
+ * amount = 1.  The Gaussian blur itself is third-party (cv::GaussianBlur, OpenCV 4.5.1, absent here; its 8-bit path uses
+ * OpenCV's own fixed-point kernel): restated as the published algorithm -- kernel size cvRound(sigma*6 + 1) | 1 = 7, taps
+ * exp(-x^2 / (2 sigma^2)) normalised, BORDER_REFLECT_101, separable, each pass rounded to 8 bit -- PARITY UNPINNED.
+ * The rest is the reference's own arithmetic: lowContrast = |src - blurred| < threshold with the uchar subtraction
+ * SATURATING at 0 (so src < blurred always counts as low contrast), sharpened = saturate(src*(1+amount) - blurred*amount). */
+static inline int orc_reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+static inline uint8_t orc_sat_u8(float v)
+{
+    float r = nearbyintf(v); /* cvRound: round half to even */
+    return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+}
+void orc_sharpenImg(const uint8_t* img, uint8_t* result, uint8_t* tmp, int rows, int cols, int ch, int stepIn, int stepOut)
+{
+    float taps[7], sum = 0;
+    for (int i = 0; i < 7; i++) {
+        taps[i] = expf(-(float)((i - 3) * (i - 3)) / 2.0f);
+        sum += taps[i];
+    }
+    for (int i = 0; i < 7; i++) taps[i] /= sum;
+    /* horizontal pass -> tmp (dense rows of cols*ch), vertical pass -> blurred value on the fly */
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++)
+            for (int c = 0; c < ch; c++) {
+                float a = 0;
+                for (int k = -3; k <= 3; k++) a += taps[k + 3] * (float)img[(size_t)y * stepIn + (size_t)orc_reflect101(x + k, cols) * ch + c];
+                tmp[((size_t)y * cols + x) * ch + c] = orc_sat_u8(a);
+            }
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++)
+            for (int c = 0; c < ch; c++) {
+                float a = 0;
+                for (int k = -3; k <= 3; k++) a += taps[k + 3] * (float)tmp[((size_t)orc_reflect101(y + k, rows) * cols + x) * ch + c];
+                int blurred = orc_sat_u8(a);
+                int src = img[(size_t)y * stepIn + (size_t)x * ch + c];
+                int diff = src - blurred;
+                if (diff < 0) diff = 0; /* uchar subtraction saturates; abs() of that */
+                int sharp = 2 * src - blurred;
+                sharp = sharp < 0 ? 0 : (sharp > 255 ? 255 : sharp);
+                result[(size_t)y * stepOut + (size_t)x * ch + c] = (uint8_t)(diff < 5 ? src : sharp);
+            }
+}
+
 /* gray = 0.299 R + 0.587 G + 0.114 B (the weights of the cv::COLOR_BGR2GRAY
  * call at test_opencv/main.cpp:866-867), float3 pitched -> float pitched. */
 void orc_rgbToGray(const of3* in, int inPitch, float* out, int outPitch, int width, int height)

@@ -81,3 +81,48 @@ def test_cli_on_the_bundled_city_frames(tmp_path):
     torch.cuda.synchronize()
     assert np.array_equal(q.cpu().numpy(), out)
     pipe.close()
+
+
+def test_image_readers_against_an_independent_decoder(tmp_path):
+    """apps/image_io.hpp (PNG, PNM, baseline JPEG readers of the CLI) through apps/imgconv, against PIL: the bundled city
+    PNGs decode exactly, the reference's "car" JPEGs (finalProject/Project/car/[1-4].jpg, copied as data fixtures: baseline
+    SOF0, YCbCr 4:2:0) to within one level of libjpeg's output."""
+    from PIL import Image
+    conv = os.path.join(ROOT, "apps", "imgconv")
+    if not os.path.exists(conv):
+        pytest.skip("apps/imgconv not built")
+    gold = os.path.join(ROOT, "tests", "golden")
+    for rel, exact in [("city/img_000002.png", True)] + [(f"car/{n}.jpg", False) for n in (1, 2, 3, 4)]:
+        out = tmp_path / "o.ppm"
+        subprocess.check_call([conv, os.path.join(gold, rel), str(out)])
+        a = np.asarray(Image.open(out)).astype(int)
+        b = np.asarray(Image.open(os.path.join(gold, rel)).convert("RGB")).astype(int)
+        assert a.shape == b.shape
+        d = np.abs(a - b)
+        if exact:
+            assert d.max() == 0
+        else:
+            assert d.max() <= 2 and d.mean() < 0.05, (rel, d.max(), d.mean())
+    # not an image / truncated file: rejected, no crash
+    bad = tmp_path / "bad.jpg"
+    bad.write_bytes(open(os.path.join(gold, "car/1.jpg"), "rb").read()[:300])
+    assert subprocess.run([conv, str(bad), str(tmp_path / "x.ppm")], capture_output=True).returncode != 0
+
+
+@pytest.mark.gpu
+def test_cli_car_burst_from_jpeg(tmp_path):
+    """`multi_frame_sr farneback car 3` on the reference's own car/1..4.jpg (multi_frame_sr.cpp:155-159): decodes the JPEGs,
+    fuses the four 130x228 frames (cropped to 128x228) and writes both result PNGs."""
+    import shutil
+    from PIL import Image
+    assert os.path.exists(CLI)
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", "car"), tmp_path / "car")
+    p = subprocess.run([CLI, "farneback", "car", "3"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "car/1.jpg, [130 x 228]" in p.stdout and "car/4.jpg, [130 x 228]" in p.stdout
+    out = np.asarray(Image.open(tmp_path / "car_farneback_sr_result.png"))
+    assert out.shape == (456, 256, 3)
+    ref = np.asarray(Image.open(tmp_path / "car" / "1.jpg").convert("RGB"))[:, :128]
+    # the x2 result is the reference frame up-sampled and denoised: its 2x2-binned version stays close to frame 1
+    binned = out.reshape(228, 2, 128, 2, 3).mean((1, 3))
+    assert np.abs(binned[8:-8, 8:-8] - ref[8:-8, 8:-8]).mean() < 12.0

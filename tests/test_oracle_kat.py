@@ -330,3 +330,26 @@ def test_prealign_recovers_a_known_rotation(angle, tx, ty):
     assert abs(np.degrees(res[2]) - angle) < 0.2
     assert abs(res[0] - tx) <= 1.0 and abs(res[1] - ty) <= 1.0
     assert res[3] == np.cos(np.float32(res[2]), dtype=np.float32) or abs(res[3] - np.cos(res[2])) < 1e-6
+
+
+def test_sharpenImg_known_answers(orc):
+    """sharpenImg (test_opencv/main.cpp:525-534): a constant image is its own blur and comes back unchanged; a step edge is
+    sharpened only on its bright side (the uchar subtraction src - blurred saturates at 0, so the dark side always counts
+    as low contrast and is copied through) and by exactly src - blurred there."""
+    flat = np.full((9, 11, 1), 77, np.uint8)
+    out = np.zeros_like(flat)
+    orc.call("sharpenImg", flat, out, np.zeros_like(flat), 9, 11, 1, 11, 11)
+    assert (out == 77).all()
+    edge = np.zeros((8, 20, 1), np.uint8)
+    edge[:, :10] = 50
+    edge[:, 10:] = 150
+    out = np.zeros_like(edge)
+    tmp = np.zeros_like(edge)
+    orc.call("sharpenImg", edge, out, tmp, 8, 20, 1, 20, 20)
+    assert (out[:, :10] == 50).all()                 # dark side: src < blurred -> "low contrast" -> copied
+    assert (out[:, 10] > 150).all() and (out[:, 14:] == 150).all()
+    # 7 taps exp(-x^2/2) normalised, both passes rounded: column 10 sees three 50s under the left taps
+    t = np.exp(-np.arange(-3, 4) ** 2 / 2.0)
+    t /= t.sum()
+    b = int(np.rint(50 * t[:3].sum() + 150 * t[3:].sum()))
+    assert out[0, 10] == min(2 * 150 - b, 255)

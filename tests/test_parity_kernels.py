@@ -1076,6 +1076,29 @@ def test_glue_stages(orc, hip):
     np.testing.assert_array_equal(o, h)
 
 
+def test_sharpenImg_unsharp_mask(orc, hip):
+    """sharpenImg (test_opencv/main.cpp:525-534) on device u8 vs the oracle: identical bytes (integer decisions on float
+    tap sums that are taken in the same order; the blur's rounding is RNE on both sides)."""
+    r = rng(77)
+    rows, cols, ch = 37, 53, 3
+    img = r.integers(0, 256, (rows, cols, ch), dtype=np.uint8)
+    img[10:20, 10:30] = 200          # flat block: low contrast -> copied through
+    img[:, 40:] = np.clip(img[:, 40:].astype(int) // 8 + 100, 0, 255).astype(np.uint8)
+    o = np.zeros_like(img)
+    h = np.zeros_like(img)
+    tmp_o, tmp_h = np.zeros_like(img), np.zeros_like(img)
+    orc.call("sharpenImg", img, o, tmp_o, rows, cols, ch, cols * ch, cols * ch)
+    hip.call("sharpenImg", img, h, tmp_h, rows, cols, ch, cols * ch, cols * ch)
+    np.testing.assert_array_equal(tmp_o, tmp_h)
+    np.testing.assert_array_equal(o, h)
+    assert (o != img).mean() > 0.3 and (o[12:18, 14:26] == 200).all()
+    # known answer: a constant image is its own blur -> returned unchanged
+    flat = np.full((9, 11, 1), 77, np.uint8)
+    out = np.zeros_like(flat)
+    orc.call("sharpenImg", flat, out, np.zeros_like(flat), 9, 11, 1, 11, 11)
+    assert (out == 77).all()
+
+
 def test_gaussin_filter_1D_host(orc, hip):
     import ctypes
     for sigma in [0.0, 0.5, 1.0, 2.7, 100.0]:

@@ -532,3 +532,55 @@ def test_joint_minimiser_burst_matches_oracle(ref_index):
     assert _psnr(p_out.cpu().numpy(), h["out"]) > 35.0
     pipe.close()
     plain.close()
+
+
+def test_frame_source_callback_equals_push_api():
+    """mfsr_burst_process_source: the pull model of the reference's FrameSource subclass (multi_frame_sr.cpp:18-49: nextFrame
+    copies the next device frame into the caller's buffer, leaves it empty when exhausted; reset rewinds).  Same result as
+    pushing the same frames with add_frame; a source that runs dry early gives the burst of the frames it delivered."""
+    import ctypes
+    import torch
+    from multi_frame_super_resolution_amd import capi, synth
+    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, default_config
+    dev = torch.device("cuda:0")
+    W, H, N = 320, 256, 6
+    frames = [f.to(dev) for f in synth.make_burst(W, H, N, seed=37)[0]]
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    NEXT = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+    RESET = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+
+    class Source(ctypes.Structure):
+        _fields_ = [("next_frame", NEXT), ("reset", RESET), ("user", ctypes.c_void_p)]
+
+    for available in (N, 4):
+        state = {"i": 0, "resets": 0}
+
+        def next_frame(user, dst, stream):
+            if state["i"] >= available:
+                return 0
+            f = frames[state["i"]]
+            state["i"] += 1
+            return 1 if hip.hipMemcpyAsync(dst, f.data_ptr(), W * H * 2, 3, stream) == 0 else -1
+
+        def reset(user):
+            state["i"] = 0
+            state["resets"] += 1
+
+        src = Source(NEXT(next_frame), RESET(reset), None)
+        cfg = default_config(W, H, N, scale=2)
+        cfg.uploadRing = 3
+        pipe = BurstPipeline(cfg, dev)
+        used = ctypes.c_int(0)
+        for rep in range(2):
+            pipe.L.burst_process_source(pipe._h, ctypes.byref(src), pipe._img_out.data_ptr(), pipe._total_weights.data_ptr(), None,
+                                        pipe.out16.data_ptr(), ctypes.byref(used), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert used.value == available and state["resets"] == rep + 1
+        got = pipe.out16.clone()
+        pipe.close()
+        wcfg = default_config(W, H, available, scale=2)
+        plain = BurstPipeline(wcfg, dev)
+        _, want = plain.process(frames[:available])
+        assert torch.equal(got, want), available
+        plain.close()

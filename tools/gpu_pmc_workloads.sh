@@ -1,0 +1,23 @@
+#!/bin/bash
+# PMC passes of the warp+fuse launches for every bench workload (runs on the GPU box through gpurun):
+#   pass 1: SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES   pass 2: FETCH_SIZE   pass 3: WRITE_SIZE
+# (separate passes, kernel-trace only, as MI355X_MICROARCH.md prescribes), restricted to the accumulate kernels.
+# Usage: tools/gpu_pmc_workloads.sh <tag> [workload ...]   -> gpurun_out/<tag>/<workload>/p{1,2,3}, summary by tools/pmc_fuse_summary.py
+set -u
+tag=${1:-r02pmc}
+shift || true
+wls=${@:-4k16_rggb_x2 4k16_rggb_x4 8k8_rggb_x2 1080p5_gray_x2}
+export TMPDIR=/tmp
+for wl in $wls; do
+  out=gpurun_out/$tag/$wl
+  mkdir -p "$out"
+  B="python3 bench.py --workload $wl --no-cpu-baseline --no-e2e --steps 1 --warmup 0"
+  i=0
+  for grp in "SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    timeout -k 10 300 rocprofv3 --pmc $grp --kernel-include-regex "accumulate" --output-format csv -d "$out/p$i" -- $B > "$out/p$i.log" 2>&1 \
+      || { echo "$wl pass $i failed"; tail -3 "$out/p$i.log"; exit 1; }
+    echo "$wl pass $i done"
+  done
+done
+python3 tools/pmc_fuse_summary.py gpurun_out/$tag $wls

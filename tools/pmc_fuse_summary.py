@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Summarise the PMC passes of tools/gpu_pmc_workloads.sh: per workload, HBM bytes and VALU wave-instructions per warp+fuse
+LAUNCH (= one tile/strip kernel dispatch + the margin-kernel dispatches of the frames it fuses), and write
+<dir>/summary.txt + <dir>/fuse_traffic.json (the entries bench.py reads from profiles/fuse_traffic.json).
+
+gfx950 corrections of MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KB; HBM bytes = 2 * FETCH_SIZE * 1024 +
+WRITE_SIZE * 1024 (the fetch counter sees half of the read traffic on this part)."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+root, wls = sys.argv[1], sys.argv[2:]
+res, lines = {}, []
+for wl in wls:
+    per = collections.defaultdict(lambda: collections.defaultdict(list))   # kernel -> counter -> values per dispatch
+    for f in glob.glob(f"{root}/{wl}/p*/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    main = [k for k in per if "Margin" not in k]
+    margin = [k for k in per if "Margin" in k]
+    if not main:
+        continue
+    k = max(main, key=lambda n: sum(per[n].get("SQ_INSTS_VALU", [0])))
+    n_main = sum(len(per[m]["SQ_INSTS_VALU"]) for m in main)   # every tile / strip dispatch (an odd burst ends with a 1-frame one)
+    n_margin = sum(len(per[m]["SQ_INSTS_VALU"]) for m in margin)
+
+    def per_launch(counter):
+        tot = sum(sum(per[m].get(counter, [])) for m in main) + sum(sum(per[m].get(counter, [])) for m in margin)
+        return tot / max(n_main, 1)
+
+    fetch, write, valu = per_launch("FETCH_SIZE"), per_launch("WRITE_SIZE"), per_launch("SQ_INSTS_VALU")
+    hbm = 2 * fetch * 1024 + write * 1024
+    res[wl] = {"hbm_bytes_per_launch": int(hbm), "valu_wave_insts_per_launch": int(valu),
+               "source": f"rocprofv3 --pmc passes of tools/gpu_pmc_workloads.sh ({(re.search(r"k_\w+", k) or [k])[0]}: {n_main} dispatches + "
+                         f"{n_margin} margin dispatches per burst)"}
+    lines.append(f"{wl}: kernel {k[:90]}")
+    lines.append(f"  dispatches per burst: {n_main} (+{n_margin} margin); per launch: FETCH_SIZE {fetch:.0f} KB, WRITE_SIZE {write:.0f} KB, "
+                 f"HBM bytes (2*F+W) {hbm / 1e9:.3f} GB, SQ_INSTS_VALU {valu:.4g}, waves {per_launch('SQ_WAVES'):.0f}")
+open(f"{root}/summary.txt", "w").write("\n".join(lines) + "\n")
+json.dump(res, open(f"{root}/fuse_traffic.json", "w"), indent=1)
+print("\n".join(lines))
