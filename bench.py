@@ -211,7 +211,11 @@ def main():
     if args.async_fuse:
         cfg.asyncFuse = 1
     if world == 1:
-        cfg.uploadRing = 4      # device slots for --h2d and the end-to-end leg (mfsr_burst_*_host); unused by the resident run
+        # device slots for --h2d and the end-to-end leg (mfsr_burst_*_host); unused by the resident run.  16 slots (the
+        # maximum): a whole 16-frame burst uploads without waiting for a slot (11.2 ms per 4K burst incl. the download of the
+        # result, against 14.9 / 15.6 ms with 4 / 8 slots; 8K x 8 is PCIe-bound at 19.2 ms whatever the depth,
+        # profiles/r02_h2d_ring_sweep.txt)
+        cfg.uploadRing = int(os.environ.get("MFSR_UPLOAD_RING", "16"))
     exchange = "stripes" if args.exchange == "auto" else args.exchange
     dist_impl = "torch" if backend == "gloo" else args.dist_impl
     use_cabi_dist = world > 1 and dist_impl == "rccl"
@@ -315,6 +319,8 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        if h2d:
+            pipe.host_sync()      # the last image's download runs on the burst's own stream
 
     if world > 1:  # bring the RCCL communicator up outside the timed region even with --warmup 0
         dist.all_reduce(torch.zeros(1, device=dev))
@@ -372,7 +378,7 @@ def main():
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             pipe.process_host(host)
-            torch.cuda.synchronize()
+            pipe.host_sync()
             if i >= 5:
                 ts.append(time.perf_counter() - t1)
         med = statistics.median(ts)
@@ -435,7 +441,7 @@ def main():
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" + (", streamed from pinned host memory (library copy stream, 4-slot device ring)" if h2d else
+            "data": "synthetic" + (", streamed from pinned host memory (library copy stream, device ring)" if h2d else
                                    ", frames resident in HBM"),
             "config": {
                 "workload": f"{n_frames}-frame {W}x{H} {'gray' if mono else 'RGGB u16'} burst -> x{s} "

@@ -409,7 +409,7 @@ typedef struct {
     int32_t applyGamma;
     int32_t fused;           /* 1: fused MI355X kernels; 0: one launch per reference kernel */
     int32_t pairFrames;      /* 1: add_frame fuses frames two at a time (see mfsr_burst_add_frame) */
-    int32_t asyncFuse;       /* 1: the warp+fuse launches run on a stream owned by the burst, concurrently with the
+    int32_t asyncFuse;       /* 1 (default): the warp+fuse launches run on a stream owned by the burst, concurrently with the
                                 alignment of the following frames on the caller's stream (see mfsr_burst_add_frame) */
     int32_t preAlign;        /* 1: estimate a global base shift + rotation per moved frame (mfsr_preAlign) and feed it to
                                 the tile tracker and the flow field (baseShift / baseRotation of kernel.cu:324, opticalFlow.cu:48) */
@@ -472,9 +472,12 @@ int mfsr_burst_finish_rows(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_
 int mfsr_burst_set_reference_host(mfsr_burst* b, const uint16_t* hostRaw, mfsr_stream_t stream);
 int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw, int isReference, mfsr_float3* imgOut,
                               mfsr_float3* totalWeights, mfsr_stream_t stream);
-/* mfsr_burst_finish into out16Dev (device) followed by its D2H copy into out16Host on the same stream */
+/* mfsr_burst_finish into out16Dev (device), then its D2H copy into out16Host on a stream the burst owns, so that the next
+ * burst's uploads and kernels overlap the download (full-duplex PCIe).  out16Host is complete after
+ * mfsr_burst_host_sync(b) (blocks the HOST on the download); out16Dev must not be written by the caller before that. */
 int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights, uint16_t* out16Dev,
                            uint16_t* out16Host, mfsr_stream_t stream);
+int mfsr_burst_host_sync(mfsr_burst* b);
 /* ---- building blocks of stripe-sharded bursts (multi-GPU, include/mfsr_dist.h): a frame is ALIGNED on the rank that
  * holds it (flow field + certainty mask into caller buffers, no accumulation), the ranks exchange the rows of raw / flow /
  * mask their stripes need, and every rank FUSES all frames, in frame order, onto its own stripe of HR rows -- the

@@ -804,7 +804,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
 // mask per tap column (none for it = 0, all for it = 4), applied to the weights as in strip_pixel.
 // Each site is its own CFA-position class (relative to the parity of (x0, y0)).  K8 = X & 7 is the
 // pixel's position in its certainty cell (8 HR pixels at scale 4), K8 & 3 its position in the strip.
-template <int K8, int CFA, typename MaskF>
+template <int K8, int CFA, bool PARITY = false, typename MaskF>
 __device__ __forceinline__ void strip_pixel4(int X, int Y, int sx, int sy, float kx, float ky, float kz,
                                               const uint16_t* __restrict__ raw, int dimX, MaskF mval,
                                               const StripLevels& lv, float* accP, float* accW)
@@ -841,12 +841,25 @@ __device__ __forceinline__ void strip_pixel4(int X, int Y, int sx, int sy, float
     for (int jt = 0; jt < 5; jt++) {
         const uint32_t mya = mQ ^ my[jt];  // absolute y parity of the site row this tap row lands on
         float Ee[2], Eo[2];
+        if constexpr (PARITY) {
+            // CFA position (y parity << 1 | x parity) of site column 0 on this tap row; tap row jt sits on site row
+            // ((qy & 3) + jt) >> 2, whose parity is Q flipped when that is 1
+            const int ph = qy & 3;
+            const int flip = jt == 0 ? 0 : (jt == 4 ? 1 : (jt == 1 ? (ph == 3) : (jt == 2 ? (ph >> 1) : (ph != 0))));
+            const int e = (((y0 & 1) ^ flip) << 1) | (x0 & 1);
 #pragma unroll
-        for (int c = 0; c < (twoCells ? 2 : 1); c++) {
-            float m[3];
+            for (int c = 0; c < (twoCells ? 2 : 1); c++) {
+                Ee[c] = mval(jt, cellLo + c, e);
+                Eo[c] = mval(jt, cellLo + c, e ^ 1);
+            }
+        } else {
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) m[ch] = mval(jt, cellLo + c, ch);
-            resolve_certainty<CFA>(mya, mP, m, Ee[c], Eo[c]);
+            for (int c = 0; c < (twoCells ? 2 : 1); c++) {
+                float m[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) m[ch] = mval(jt, cellLo + c, ch);
+                resolve_certainty<CFA>(mya, mP, m, Ee[c], Eo[c]);
+            }
         }
         // weights per (site column, cell), then one multiply with the certainty of that pair
         float lo[2] = {0.0f, 0.0f}, hi[2] = {0.0f, 0.0f};
@@ -929,7 +942,9 @@ __global__ void __launch_bounds__(256, 3)
             for (int n = 0; n < NF; n++) {
                 sF[n][rr][c] = row_ptr((const float2*)fr.f[n].shifts.ptr, fr.f[n].shifts.pitch, fy)[fx];
                 const float4 m = row_ptr(fr.f[n].mask, strideMask, clampi(gy, 0, mh - 1))[clampi(gx, 0, mw - 1)];
-                sM[n][rr][c] = make_float4(sane(m.x), sane(m.y), sane(m.z), 0.0f);
+                const float mc[3] = {sane(m.x), sane(m.y), sane(m.z)};  // by CFA position, see k_accumulate2xTile
+                sM[n][rr][c] = make_float4(mc[Cfa<CFA>::col(0, 0)], mc[Cfa<CFA>::col(0, 1)], mc[Cfa<CFA>::col(1, 0)],
+                                          mc[Cfa<CFA>::col(1, 1)]);
             }
         }
 #pragma unroll
@@ -1045,21 +1060,21 @@ __global__ void __launch_bounds__(256, 3)
 #pragma unroll
             for (int k = 0; k < 4; k++) asm volatile("" : "+v"(kxa[k]), "+v"(kya[k]), "+v"(kza[k]));
             // certainty: LDS row of the mask row that tap row jt reads, column lx + cell
-            auto mval = [&](int jt, int cell, int ch) {
+            auto mval = [&](int jt, int cell, int e) {
                 const int mr = ((yq + jt - 2 + 8) >> 3);
                 const float* p = (const float*)&sM[n][mr][lx + cell];
-                return p[ch];
+                return p[e];
             };
             if (h == 0) {
-                strip_pixel4<0, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
-                strip_pixel4<1, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
-                strip_pixel4<2, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
-                strip_pixel4<3, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<0, CFA, true>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<1, CFA, true>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<2, CFA, true>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<3, CFA, true>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
             } else {
-                strip_pixel4<4, CFA>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
-                strip_pixel4<5, CFA>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
-                strip_pixel4<6, CFA>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
-                strip_pixel4<7, CFA>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<4, CFA, true>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<5, CFA, true>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<6, CFA, true>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
+                strip_pixel4<7, CFA, true>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
             }
         }
     }

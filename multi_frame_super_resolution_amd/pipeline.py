@@ -122,6 +122,10 @@ class BurstPipeline:
             self.add_frame(frames[k], k == ref)
         return self.finish()
 
+    def host_sync(self):
+        """Block the host until the image of the last process_host has landed in host memory."""
+        self.L.burst_host_sync(self._h)
+
     def process_joint(self, frames: Sequence[torch.Tensor]):
         """Whole burst with the joint shift minimiser in the loop (mfsr_burst_process_joint: every neighbouring pair is
         measured besides the (reference, k) pairs; per-tile least squares with outlier rejection gives the tile shifts)."""
@@ -180,7 +184,7 @@ class BurstPipeline:
     def process_host(self, host_frames: Sequence[torch.Tensor], out16_host: Optional[torch.Tensor] = None):
         """Whole burst from HOST frames (pin them: ``t.pin_memory()``) to the u16 HR image in host memory:
         mfsr_burst_set_reference_host / add_frame_host / finish_host.  Returns the (pinned) host image; it is complete
-        once the current stream has been synchronised."""
+        after ``host_sync()`` (the download runs on a stream of its own so that the next burst overlaps it)."""
         if self.cfg.uploadRing <= 0:
             raise ValueError("cfg.uploadRing must be > 0 for host-frame bursts")
         for f in host_frames:

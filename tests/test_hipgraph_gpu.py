@@ -83,7 +83,7 @@ def test_config4_8k_frames_graph_replay_and_host_ring():
     host = [f.cpu().pin_memory() for f in a]
     for rep in range(2):
         got = pipe.process_host(host)
-        torch.cuda.synchronize()
+        pipe.host_sync()
         assert torch.equal(got, eager[0].cpu()), f"host-ring burst {rep} differs from the resident burst"
     # (c) the alignment locked at 8K (flow of the last frame of the first burst: recompute eagerly)
     pipe.process(a)

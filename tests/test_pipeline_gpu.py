@@ -486,7 +486,7 @@ def test_host_frame_burst_equals_device_frame_burst(ring, pair, async_fuse):
         pinned = [f.pin_memory() for f in frames]
         for rep in range(3):
             got = pipe.process_host(pinned)
-            torch.cuda.synchronize()
+            pipe.host_sync()
             assert torch.equal(got, want), (ref, rep)
             got.zero_()
         pipe.close()

@@ -33,8 +33,10 @@ for wl in wls:
 
     fetch, write, valu = per_launch("FETCH_SIZE"), per_launch("WRITE_SIZE"), per_launch("SQ_INSTS_VALU")
     hbm = 2 * fetch * 1024 + write * 1024
+    mk = re.search(r"k_\w+", k)
+    kname = mk.group(0) if mk else k
     res[wl] = {"hbm_bytes_per_launch": int(hbm), "valu_wave_insts_per_launch": int(valu),
-               "source": f"rocprofv3 --pmc passes of tools/gpu_pmc_workloads.sh ({(re.search(r"k_\w+", k) or [k])[0]}: {n_main} dispatches + "
+               "source": f"rocprofv3 --pmc passes of tools/gpu_pmc_workloads.sh ({kname}: {n_main} dispatches + "
                          f"{n_margin} margin dispatches per burst)"}
     lines.append(f"{wl}: kernel {k[:90]}")
     lines.append(f"  dispatches per burst: {n_main} (+{n_margin} margin); per launch: FETCH_SIZE {fetch:.0f} KB, WRITE_SIZE {write:.0f} KB, "
