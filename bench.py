@@ -7,24 +7,26 @@ per-frame align -> robustness -> warp+fuse, exchange, finish), inputs already
 resident in HBM.  Workload at N=1 = BASELINE configs[2]: 16 frames of 3840x2160
 RGGB u16, x2 (the configuration north_star quotes its roofline target on).
 
-Multi-GPU: weak scaling over the burst dimension -- every rank aligns and fuses
-FRAMES_PER_GPU frames of ONE burst of FRAMES_PER_GPU*N frames into its private
-HR accumulators; the accumulators are summed with an RCCL reduce-scatter over
-xGMI, each rank finishes its stripe, rank 0 gathers the u16 result
-(multi_frame_super_resolution_amd/distributed.py).  `--strong` keeps the burst
-at 16 frames and shards it instead.
+Multi-GPU (--gpus N, one rank per GPU): STRONG scaling of the workload's fixed burst by default.  Every rank aligns
+frames {k : k mod N = rank}; the ranks exchange the rows of raw / flow / certainty their HR row stripes read
+(point-to-point over xGMI), every rank fuses ALL frames onto its stripe and finishes it, rank 0 collects the u16
+stripes -- bit-identical to the 1-GPU burst (include/mfsr_dist.h, csrc/dist.cpp: RCCL directly; --dist-impl torch runs
+the torch.distributed mirror).  --exchange reduce | reduce_scatter sum private accumulators instead; --weak shards
+frames-per-GPU x N frames.
 
 Also reported on the same JSON line:
-  roofline     : the warp+fuse launches (accumulateSuperResFullN: two frames per launch with frame
-                 pairing), HIP-event timed around every launch inside the timed region, algorithmic
-                 bytes = per-frame figure x frames per launch, vs the 8 TB/s HBM peak;
-  cpu_baseline : the CPU oracle pipeline ("port" of the same algorithm; the
-                 reference's own CPU path is third-party OpenCV BTVL1, absent here)
-                 timed on the host cores on a bounded sample of the same workload, plus the parity of
-                 the HIP path against it on that sample (PSNR, fractions off by more than 1 LSB).
+  end_to_end   : SURVEY.md 8(d)'s definition -- first H2D enqueue to D2H of the result complete, one burst in flight,
+                 median of 20 (frames in pinned host memory through mfsr_burst_*_host);
+  roofline     : the warp+fuse launches (two frames per launch), HIP-event timed around every launch inside the timed
+                 region; frac = bytes a launch MUST move / time / 8 TB/s; "bound": "valu" with the VALU-issue ceiling
+                 from the PMC instruction count; traffic = PMC HBM bytes; reference_structure = SURVEY's per-frame RMW
+                 accounting (what the reference's kernel would move), labelled as such;
+  cpu_baseline : the CPU oracle pipeline ("port" of the same algorithm; the reference's own CPU path is third-party
+                 OpenCV BTVL1, absent here) timed on the host cores on a bounded sample of the same workload, plus the
+                 flip-set parity classification of the HIP path against it on that sample (tests/flipset.py).
 
-Other modes (not the contract's `value`): --h2d (frames streamed from pinned host memory), --no-pair,
---async-fuse, --unfused, --workload {1080p5_gray_x2, 4k16_rggb_x4, 8k8_rggb_x2}, and
+Other modes (not the contract's `value`): --h2d (every burst's frames start in pinned host memory), --no-pair,
+--no-async-fuse, --unfused, --workload {1080p5_gray_x2, 4k16_rggb_x4, 8k8_rggb_x2}, and
 MFSR_DIST_BACKEND=gloo (functional rehearsal of the multi-rank schedule on fewer GPUs than ranks).
 """
 from __future__ import annotations
@@ -152,6 +154,7 @@ def main():
     ap.add_argument("--dist-impl", default="rccl", choices=["rccl", "torch"],
                     help="N > 1: rccl = the C-ABI multi-GPU layer (libmfsr_dist.so, RCCL directly); torch = its torch.distributed "
                          "mirror (distributed.py; also what MFSR_DIST_BACKEND=gloo rehearsals use)")
+    ap.add_argument("--force-dist", action="store_true", help="N=1: run the step through mfsr_dist_* (one-rank communicator) -- rehearsal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the H2D->D2H end-to-end leg (median of 20 bursts)")
     ap.add_argument("--cpu-sample-frames", type=int, default=4)
@@ -161,9 +164,9 @@ def main():
                          "align+fuse of burst i+1")
     ap.add_argument("--force-pipelined", action="store_true", help="use the two-context pipelined step loop even at N=1 (test)")
     ap.add_argument("--no-pair", action="store_true", help="cfg.pairFrames = 0: one warp+fuse launch per frame (the reference's structure)")
-    ap.add_argument("--async-fuse", action="store_true",
-                    help="cfg.asyncFuse: warp+fuse on the burst's own stream, overlapping the alignment of the next frames "
-                         "(+5 % burst throughput, the fuse launches themselves get 17 % slower; off by default)")
+    ap.add_argument("--async-fuse", action="store_true", help="(default since round 2: cfg.asyncFuse = 1) accepted for compatibility")
+    ap.add_argument("--no-async-fuse", action="store_true",
+                    help="cfg.asyncFuse = 0: warp+fuse launches on the caller's stream instead of the burst's own (A/B: -5 %)")
     ap.add_argument("--h2d", action="store_true",
                     help="N=1 only: frames start in pinned HOST memory and stream through a 4-deep device ring on a copy "
                          "stream (the PCIe-inclusive rate quoted in DESIGN.md; `value` of the contract is the HBM-resident run)")
@@ -208,8 +211,8 @@ def main():
     cfg.fused = 0 if args.unfused else 1
     if args.no_pair:
         cfg.pairFrames = 0
-    if args.async_fuse:
-        cfg.asyncFuse = 1
+    if args.no_async_fuse:
+        cfg.asyncFuse = 0
     if world == 1:
         # device slots for --h2d and the end-to-end leg (mfsr_burst_*_host); unused by the resident run.  16 slots (the
         # maximum): a whole 16-frame burst uploads without waiting for a slot (11.2 ms per 4K burst incl. the download of the
@@ -218,8 +221,12 @@ def main():
         cfg.uploadRing = int(os.environ.get("MFSR_UPLOAD_RING", "16"))
     exchange = "stripes" if args.exchange == "auto" else args.exchange
     dist_impl = "torch" if backend == "gloo" else args.dist_impl
-    use_cabi_dist = world > 1 and dist_impl == "rccl"
+    # --force-dist: the multi-GPU code path with a world of one rank (one-rank RCCL communicator): rehearsal of what the
+    # driver's N > 1 runs execute, on a single GPU
+    use_cabi_dist = (world > 1 or args.force_dist) and dist_impl == "rccl"
     pipe = None if use_cabi_dist else BurstPipeline(cfg, dev)
+    if use_cabi_dist and world == 1:
+        args.no_e2e = True
 
     # synthetic burst: one scene (same seed on every rank), this rank's frames only
     seed = 1234 + 2
@@ -244,7 +251,8 @@ def main():
             D.dist_get_unique_id(buf)
             uid = torch.tensor(list(buf), dtype=torch.uint8)
         uid = uid.to(dev)
-        dist.broadcast(uid, src=0)
+        if world > 1:
+            dist.broadcast(uid, src=0)
         uid_c = (ctypes.c_uint8 * capi.DIST_ID_BYTES)(*uid.cpu().tolist())
         nbytes = D.dist_workspace_bytes(ctypes.byref(cfg), world)
         d_ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
@@ -272,9 +280,9 @@ def main():
         ev_done = [torch.cuda.Event() for _ in pipes]   # exchange + finish of context j done (side stream)
         used = [False for _ in pipes]
 
-    h2d = args.h2d and world == 1
+    h2d = args.h2d and world == 1 and pipe is not None
     host = None
-    if world == 1:
+    if world == 1 and pipe is not None:
         order = sorted(frames.keys())
         host = [frames[k].cpu().pin_memory() for k in order]   # pinned host copies for --h2d / the end-to-end leg
 
@@ -335,7 +343,8 @@ def main():
             step()
             barrier()
         st = d_status.clone()
-        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        if world > 1:
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
         if int(st.item()) != 0:
             D.dist_set_raw_halo(d_h, H)
             halo_note = "whole raw frames exchanged (a flow exceeded the default 64-row halo)"
@@ -396,7 +405,7 @@ def main():
         # bytes a launch MUST move (accumulators once per launch, not once per frame) vs the reference-structure figure
         # frames fused per rank and the fraction of the HR rows a launch covers: all frames on 1/world of the rows in the
         # stripes mode, the rank's own frames on the whole grid otherwise
-        stripes_mode = world > 1 and exchange == "stripes"
+        stripes_mode = (world > 1 or use_cabi_dist) and exchange == "stripes"
         fused_per_rank = n_frames if stripes_mode else len(mine)
         row_frac = 1.0
         if stripes_mode:

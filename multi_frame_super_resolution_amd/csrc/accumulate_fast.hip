@@ -905,8 +905,12 @@ __device__ __forceinline__ void strip_pixel4(int X, int Y, int sx, int sy, float
 // constant per wave.  Staging as in the x2 kernel (64 + 2 field texels x 3 rows, column/row fractions,
 // accumulator rows through LDS-DMA); the two waves of a row share its staged segment, hence the
 // workgroup barriers around the LDS update.
+// waves per SIMD the x4 kernel's register budget is sized for with two frames per launch (one frame: 113 VGPRs = 4)
+#ifndef TILE4_WAVES2
+#define TILE4_WAVES2 3
+#endif
 template <int CFA, int NF>
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, (NF) == 1 ? 4 : TILE4_WAVES2)
     k_accumulate4xTile(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
                        Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked,
                        int tilesX, int fresh, int tileY0)
