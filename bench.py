@@ -324,6 +324,9 @@ def main():
         return out
 
     def barrier():
+        if use_cabi_dist:   # the last burst's stripes are collected on the dist context's own stream
+            D.dist_wait_output(d_h, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -63,6 +63,11 @@ int mfsr_dist_stripe(const mfsr_dist* d, int rank, int* rowBegin, int* rowEnd);
  * exceeded the raw halo of the STRIPES exchange (result invalid: raise the halo or use another mode). */
 int mfsr_dist_process_burst(mfsr_dist* d, const uint16_t* const* frames, int mode, uint16_t* out16, int* status,
                             mfsr_stream_t stream);
+/* STRIPES mode issues its RCCL calls on a stream the context owns (same order on every rank), event-linked to `stream`:
+ * the collection of burst i's stripes on rank 0 overlaps the alignment of burst i+1.  out16 / status of the LAST
+ * process_burst are complete once `stream` has passed mfsr_dist_wait_output (or after a device-wide synchronise).
+ * MFSR_DIST_OVERLAP=0 in the environment keeps every call on the caller's stream. */
+int mfsr_dist_wait_output(mfsr_dist* d, mfsr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -110,7 +111,14 @@ struct mfsr_dist {
     char* base;
     mfsr_float3 *imgOut, *totalWeights;
     uint16_t* out16;
-    int* flag;
+    int* flag;   // two ints: bursts alternate (the previous burst's all-reduce may still be in flight on the comm stream)
+    // STRIPES: every RCCL call goes to commStream, in the same order on every rank (exchange i, gather i, exchange i+1, ..),
+    // event-linked to the caller's stream, so that the gather of burst i overlaps the alignment of burst i+1
+    hipStream_t commStream;
+    hipEvent_t evAligned, evExchanged, evFinished, evGathered;
+    bool gatherPending;
+    int overlap;
+    long long burstNo;
     uint16_t* raw(int k) const { return (uint16_t*)(base + L.offRaw + up(L.rawBytes, 256) * (size_t)k); }
     mfsr_float2* flow(int k) const { return (mfsr_float2*)(base + L.offFlow + up(L.flowBytes, 256) * (size_t)k); }
     mfsr_float4* mask(int k) const { return (mfsr_float4*)(base + L.offMask + up(L.maskBytes, 256) * (size_t)k); }
@@ -163,6 +171,21 @@ extern "C" int mfsr_dist_create(mfsr_dist** out, const mfsr_config* cfg, int ran
         delete d;
         return rc;
     }
+    {
+        const char* e = getenv("MFSR_DIST_OVERLAP");
+        d->overlap = (e && e[0] == '0') ? 0 : 1;
+        hipError_t he = hipStreamCreateWithFlags(&d->commStream, hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&d->evAligned, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&d->evExchanged, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&d->evFinished, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&d->evGathered, hipEventDisableTiming);
+        if (he != hipSuccess) {
+            fprintf(stderr, "mfsr_dist: stream / event creation failed: %s\n", hipGetErrorString(he));
+            mfsr_burst_destroy(d->burst);
+            delete d;
+            return (int)he;
+        }
+    }
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
     ncclResult_t r = ncclCommInitRank(&d->comm, worldSize, u, rank);
@@ -179,7 +202,13 @@ extern "C" int mfsr_dist_create(mfsr_dist** out, const mfsr_config* cfg, int ran
 extern "C" void mfsr_dist_destroy(mfsr_dist* d)
 {
     if (!d) return;
+    if (d->commStream) (void)hipStreamSynchronize(d->commStream);
     if (d->comm) (void)ncclCommDestroy(d->comm);
+    if (d->evAligned) (void)hipEventDestroy(d->evAligned);
+    if (d->evExchanged) (void)hipEventDestroy(d->evExchanged);
+    if (d->evFinished) (void)hipEventDestroy(d->evFinished);
+    if (d->evGathered) (void)hipEventDestroy(d->evGathered);
+    if (d->commStream) (void)hipStreamDestroy(d->commStream);
     mfsr_burst_destroy(d->burst);
     delete d;
 }
@@ -229,7 +258,10 @@ static int process_stripes(mfsr_dist* d, const uint16_t* const* frames, uint16_t
     std::vector<mfsr_stripe_plan> plan(G);
     for (int p = 0; p < G; p++) D_TRY(mfsr_dist_stripe_plan(&c, G, p, d->rawHalo, &plan[p]));
     const mfsr_stripe_plan& mine = plan[me];
-    D_HIP(hipMemsetAsync(d->flag, 0, sizeof(int), st));
+    int* flag = d->flag + (d->burstNo++ & 1);
+    // A = the caller's stream (kernels), B = the comm stream (every RCCL call); with overlap off B = A
+    hipStream_t B = d->overlap ? d->commStream : st;
+    D_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
 
     // reference products on every rank, then this rank's frames: alignment only
     D_TRY(mfsr_burst_set_reference(d->burst, frames[ref], (mfsr_stream_t)st));
@@ -241,8 +273,14 @@ static int process_stripes(mfsr_dist* d, const uint16_t* const* frames, uint16_t
         D_TRY(mfsr_burst_align_frame(d->burst, frames[k], k == ref, d->flow(k), L.flowPitch, d->mask(k), L.maskPitch, (mfsr_stream_t)st));
     }
 
-    // exchange: to peer p the rows of my frames that p's stripe reads; from the owner of frame k the rows mine reads
+    // exchange (on B, after the alignment on A): to peer p the rows of my frames that p's stripe reads; from the owner of
+    // frame k the rows mine reads.  (Receive buffers: B is past gather(i-1), which waited for fuse(i-1) -- their last reader.)
+    D_HIP(hipEventRecord(d->evAligned, st));
+    D_HIP(hipStreamWaitEvent(B, d->evAligned, 0));
+    for (int k = 0; k < N; k++)
+        if (k % G != me) raws[k] = d->raw(k);
     if (G > 1) {
+        hipStream_t st = B;  // the sends / receives below go to the comm stream
         D_NCCL(ncclGroupStart());
         for (int p = 0; p < G; p++) {
             if (p == me || plan[p].rowEnd <= plan[p].rowBegin) continue;
@@ -270,13 +308,15 @@ static int process_stripes(mfsr_dist* d, const uint16_t* const* frames, uint16_t
         }
         D_NCCL(ncclGroupEnd());
     }
+    D_HIP(hipEventRecord(d->evExchanged, B));
+    D_HIP(hipStreamWaitEvent(st, d->evExchanged, 0));
 
     // every frame, in frame order, two per pass over the accumulators, onto this rank's HR rows only
     if (mine.rowEnd > mine.rowBegin) {
         // (a halo that spans the whole frame needs no check: every raw row is present)
         for (int k = 0; k < N && mine.rawRows < c.height; k++)
             D_TRY(mfsr_checkFlowBound((const mfsr_float2*)((const char*)d->flow(k) + (size_t)mine.flowRow0 * L.flowPitch), L.flowPitch, L.tw,
-                                      mine.flowRows, mine.maxFlowY, d->flag, (mfsr_stream_t)st));
+                                      mine.flowRows, mine.maxFlowY, flag, (mfsr_stream_t)st));
         const int per = c.pairFrames ? 2 : 1;
         for (int k = 0; k < N; k += per) {
             const int n = (k + per <= N) ? per : N - k;
@@ -287,14 +327,22 @@ static int process_stripes(mfsr_dist* d, const uint16_t* const* frames, uint16_t
                                        mine.rowBegin, mine.rowEnd, (mfsr_stream_t)st));
         }
         uint16_t* dst = me == 0 ? out16 : d->out16;
+        // the staging image may still be on its way to rank 0 (gather of the previous burst, on B)
+        if (d->gatherPending) D_HIP(hipStreamWaitEvent(st, d->evGathered, 0));
         D_TRY(mfsr_burst_finish_rows(d->burst, d->imgOut, d->totalWeights, nullptr, dst, mine.rowBegin, mine.rowEnd - mine.rowBegin,
                                      (mfsr_stream_t)st));
     }
+    // gather + status on B after the finish on A; the caller's stream does NOT wait for it (mfsr_dist_wait_output does):
+    // the next burst's alignment runs meanwhile
+    D_HIP(hipEventRecord(d->evFinished, st));
+    D_HIP(hipStreamWaitEvent(B, d->evFinished, 0));
     if (G > 1) {
-        D_TRY(gather_stripes(d, plan, out16, st));
-        D_NCCL(ncclAllReduce(d->flag, d->flag, 1, ncclInt32, ncclMax, d->comm, st));
+        D_TRY(gather_stripes(d, plan, out16, B));
+        D_NCCL(ncclAllReduce(flag, flag, 1, ncclInt32, ncclMax, d->comm, B));
     }
-    if (status) D_HIP(hipMemcpyAsync(status, d->flag, sizeof(int), hipMemcpyDeviceToDevice, st));
+    if (status) D_HIP(hipMemcpyAsync(status, flag, sizeof(int), hipMemcpyDeviceToDevice, B));
+    D_HIP(hipEventRecord(d->evGathered, B));
+    d->gatherPending = true;
     return MFSR_OK;
 }
 
@@ -350,5 +398,16 @@ extern "C" int mfsr_dist_process_burst(mfsr_dist* d, const uint16_t* const* fram
     D_REQUIRE(d->rank != 0 || out16 != nullptr);
     hipStream_t st = (hipStream_t)stream;
     if (mode == MFSR_DIST_STRIPES) return process_stripes(d, frames, out16, status, st);
+    if (d->gatherPending) {  // a STRIPES burst before: its gather uses the communicator on the comm stream
+        D_HIP(hipStreamWaitEvent(st, d->evGathered, 0));
+        d->gatherPending = false;
+    }
     return process_reduce(d, frames, mode, out16, status, st);
+}
+
+extern "C" int mfsr_dist_wait_output(mfsr_dist* d, mfsr_stream_t stream)
+{
+    D_REQUIRE(d != nullptr);
+    if (d->gatherPending) D_HIP(hipStreamWaitEvent((hipStream_t)stream, d->evGathered, 0));
+    return MFSR_OK;
 }

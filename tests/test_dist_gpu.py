@@ -190,7 +190,8 @@ def test_rccl_layer_with_one_rank(mode):
     ptrs = (ctypes.c_void_p * N)(*[f.data_ptr() for f in frames])
     for rep in range(2):
         D.dist_process_burst(h, ptrs, mode, out16.data_ptr(), status.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
+        D.dist_wait_output(h, torch.cuda.current_stream().cuda_stream)   # stripes: collection runs on the context's comm stream
+        torch.cuda.current_stream().synchronize()
         assert int(status.item()) == 0
         assert torch.equal(out16, want), (mode, rep)
         out16.zero_()
