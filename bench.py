@@ -380,6 +380,27 @@ def main():
         raise SystemExit("mfsr_dist: a frame's vertical flow exceeded the raw halo of the stripes exchange (status 1): the result is "
                          "invalid; use --exchange reduce_scatter or a larger halo")
 
+    # The timed region runs with cfg.asyncFuse (the default): the warp+fuse launches share the GPU with the alignment of the
+    # following frames, which stretches them.  A short extra leg times the same launches WITHOUT that overlap (launches back to
+    # back on one stream) so that the line also carries the kernel's stand-alone figure.
+    isolated = None
+    if world == 1 and rank == 0 and pipe is not None and cfg.asyncFuse and not h2d:
+        cfg_iso = default_config(W, H, n_frames, s, mono)
+        cfg_iso.fused, cfg_iso.pairFrames, cfg_iso.asyncFuse = cfg.fused, cfg.pairFrames, 0
+        p_iso = BurstPipeline(cfg_iso, dev)
+        mdist.process_burst(p_iso, frames, n_frames=n_frames)
+        torch.cuda.synchronize()
+        LIB.burst_timing(p_iso._h, 1)
+        for _ in range(3):
+            mdist.process_burst(p_iso, frames, n_frames=n_frames)
+        torch.cuda.synchronize()
+        t_ms, n_l, n_f = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_int(0)
+        LIB.burst_timing_read(p_iso._h, ctypes.byref(t_ms), ctypes.byref(n_l), ctypes.byref(n_f))
+        LIB.burst_timing(p_iso._h, 0)
+        if n_l.value:
+            isolated = {"avg_launch_ms": t_ms.value / n_l.value, "launches_timed": n_l.value}
+        p_iso.close()
+
     # SURVEY.md section 8(d)'s end-to-end figure, beside the HBM-resident `value`: wall time from the first H2D enqueue
     # to the final D2H complete, one burst at a time, median of 20 (after 5 warm-up bursts)
     e2e = None
@@ -492,6 +513,14 @@ def main():
                 "avg_launch_ms": round(k_ms, 4),
                 "launches_timed": launches.value,
                 "valu": valu,
+                "timed_region_note": ("launches of the timed region run on the burst's own stream concurrently with the alignment of the "
+                                      "following frames (cfg.asyncFuse, +5 % burst throughput), which stretches them; `isolated` = the "
+                                      "same launches back to back on one stream (3 extra bursts, cfg.asyncFuse = 0)") if isolated else None,
+                "isolated": ({"avg_launch_ms": round(isolated["avg_launch_ms"], 4), "launches_timed": isolated["launches_timed"],
+                              "achieved": round(bytes_launch / (isolated["avg_launch_ms"] * 1e-3) / 1e9, 1),
+                              "frac": round(bytes_launch / (isolated["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                              "valu_frac": (round(valu["floor_ms"] / isolated["avg_launch_ms"], 4) if valu else None)}
+                             if isolated else None),
                 "reference_structure": {
                     "bytes_per_launch": int(bytes_ref_launch), "achieved": round(achieved_ref, 1),
                     "frac": round(achieved_ref / HBM_PEAK_GBPS, 4),

@@ -54,7 +54,7 @@ class FlipSet:
         self.hrW, self.hrH = self.W * self.s, self.H * self.s
         self.tie_eps = tie_eps
         self.flips = np.zeros((self.hrH, self.hrW), bool)
-        self.n = dict(fuse_round=0, robust_round=0, robust_M=0, weight_threshold=0)
+        self.n = dict(fuse_round=0, fuse_round_actual=0, robust_round=0, robust_M=0, weight_threshold=0)
         self.frames = 0
         self.max_flow_diff = 0.0
 
@@ -80,8 +80,10 @@ class FlipSet:
         # (1)
         vh, sh = self._fuse_shifts(flow_h)
         vo, so = self._fuse_shifts(flow_o)
-        f1 = (sh != so).any(-1) | ((vh != vo).any(-1) & (_near_tie(vh, self.tie_eps) | _near_tie(vo, self.tie_eps)))
+        a1 = (sh != so).any(-1)                                    # roundings that really differ
+        f1 = a1 | ((vh != vo).any(-1) & (_near_tie(vh, self.tie_eps) | _near_tie(vo, self.tie_eps)))   # + the tie guard
         self.n["fuse_round"] += int(f1.sum())
+        self.n["fuse_round_actual"] += int(a1.sum())
         self.flips |= f1
         # (2) + (3), half resolution
         rvh, rsh = self._robust_shifts(flow_h)

@@ -15,7 +15,7 @@ for wl in $wls; do
   i=0
   for grp in "SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
-    timeout -k 10 300 rocprofv3 --pmc $grp --kernel-include-regex "accumulate" --output-format csv -d "$out/p$i" -- $B > "$out/p$i.log" 2>&1 \
+    timeout -k 10 300 rocprofv3 --pmc $grp --kernel-include-regex "${KERNEL_RE:-accumulate}" --output-format csv -d "$out/p$i" -- $B > "$out/p$i.log" 2>&1 \
       || { echo "$wl pass $i failed"; tail -3 "$out/p$i.log"; exit 1; }
     echo "$wl pass $i done"
   done
