@@ -366,6 +366,14 @@ int mfsr_trackTilesFusedBase(const float* refImg, const float* movedImg, const m
                              int maxShift, int tileSize, int tileCountX, int tileCountY, float threshold,
                              const float* refSquaredSums, const mfsr_prealign* base, float baseInvScale,
                              mfsr_stream_t stream);
+/* mfsr_trackTilesFusedBase with UpSampleShifts (B8, kernel.cu:642) folded in: every tile's pre-shift is taken inside the
+ * kernel from the previous level's shifts (oldCountX x oldCountY tiles of oldTileSize at down-sampling factor oldLevel)
+ * with B8's own arithmetic: same bits, one launch and one buffer less per pyramid level */
+int mfsr_trackTilesFusedUp(const float* refImg, const float* movedImg, const mfsr_float2* coarseShifts, int coarsePitch,
+                           int oldLevel, int newLevel, int oldCountX, int oldCountY, int oldTileSize, mfsr_float2* coordinates,
+                           int coordinatesPitch, int imgWidth, int imgHeight, int imgPitch, int maxShift, int tileSize,
+                           int tileCountX, int tileCountY, float threshold, const float* refSquaredSums,
+                           const mfsr_prealign* base, float baseInvScale, mfsr_stream_t stream);
 /* mfsr_CreateFlowFieldFromTiles (opticalFlow.cu:48) with baseShift / baseRotation taken from *base (device) */
 int mfsr_CreateFlowFieldFromTilesBase(mfsr_float2* outImg, mfsr_tex2d texObjShiftXY, int imgWidth, int imgHeight,
                                       int imgPitch, const mfsr_prealign* base, mfsr_stream_t stream);

@@ -597,6 +597,15 @@ static int track_tiles(mfsr_burst* b, const mfsr_prealign* hostBase, mfsr_stream
         const int T = c.tileSize[l], S = c.maxShift[l];
         const int tiles = L.tcx[l] * L.tcy[l];
         const mfsr_float2* pre = nullptr;
+        if (c.fused && l > 0) {
+            // B8 folded into the tracker: the pre-shifts come straight from the previous level's shifts
+            TRY(mfsr_trackTilesFusedUp((const float*)ref.ptr, (const float*)mov.ptr, (const mfsr_float2*)L.shifts[l - 1].ptr,
+                                       L.shifts[l - 1].pitch, c.levelFactor[l - 1], c.levelFactor[l], L.tcx[l - 1], L.tcy[l - 1],
+                                       c.tileSize[l - 1], (mfsr_float2*)L.shifts[l].ptr, L.shifts[l].pitch, ref.w, ref.h, ref.pitch, S,
+                                       T, L.tcx[l], L.tcy[l], c.minimumThreshold, L.refSq[l], c.preAlign ? L.preResult : nullptr,
+                                       1.0f / (float)c.levelFactor[l], stream));
+            continue;
+        }
         if (l > 0) {
             TRY(mfsr_UpSampleShifts((const mfsr_float2*)L.shifts[l - 1].ptr, (mfsr_float2*)L.pre[l].ptr,
                                     L.shifts[l - 1].pitch, L.pre[l].pitch, c.levelFactor[l - 1], c.levelFactor[l],

@@ -387,11 +387,14 @@ extern "C" int mfsr_findMinimum(const float* shiftImage, mfsr_float2* coordinate
 __global__ void __launch_bounds__(256)
     k_UpSampleShifts(const float2* __restrict__ inShift, float2* __restrict__ outShift, int inPitch, int outPitch,
                      int oldLevel, int newLevel, int oldCountX, int oldCountY, int newCountX, int newCountY,
-                     int oldTileSize, int newTileSize)
+                     int oldTileSize, int newTileSize);
+
+// B8 for one tile of the new level (kernel.cu:642-688): shared by k_UpSampleShifts and the fused tracker, which takes
+// the pre-shift of its tiles straight from the previous level's shifts (no separate launch, no pre-shift buffer)
+__device__ __forceinline__ float2 upsample_shift_at(const float2* __restrict__ inShift, int inPitch, int oldLevel, int newLevel,
+                                                    int oldCountX, int oldCountY, int oldTileSize, int newTileSize, int newBlockX,
+                                                    int newBlockY)
 {
-    const int newBlockX = blockIdx.x * blockDim.x + threadIdx.x;
-    const int newBlockY = blockIdx.y * blockDim.y + threadIdx.y;
-    if (newBlockX >= newCountX || newBlockY >= newCountY) return;
     const float factor = (float)oldLevel * (float)oldTileSize / (float)(newLevel * newTileSize);
     const float oldX = (float)newBlockX / factor;
     const float oldY = (float)newBlockY / factor;
@@ -416,7 +419,19 @@ __global__ void __launch_bounds__(256)
     old.y = temp1 + (temp2 - temp1) * wy;
     old.x *= (float)oldLevel / (float)newLevel;
     old.y *= (float)oldLevel / (float)newLevel;
-    row_ptr(outShift, outPitch, newBlockY)[newBlockX] = old;
+    return old;
+}
+
+__global__ void __launch_bounds__(256)
+    k_UpSampleShifts(const float2* __restrict__ inShift, float2* __restrict__ outShift, int inPitch, int outPitch,
+                     int oldLevel, int newLevel, int oldCountX, int oldCountY, int newCountX, int newCountY,
+                     int oldTileSize, int newTileSize)
+{
+    const int newBlockX = blockIdx.x * blockDim.x + threadIdx.x;
+    const int newBlockY = blockIdx.y * blockDim.y + threadIdx.y;
+    if (newBlockX >= newCountX || newBlockY >= newCountY) return;
+    row_ptr(outShift, outPitch, newBlockY)[newBlockX] =
+        upsample_shift_at(inShift, inPitch, oldLevel, newLevel, oldCountX, oldCountY, oldTileSize, newTileSize, newBlockX, newBlockY);
 }
 
 extern "C" int mfsr_UpSampleShifts(const mfsr_float2* inShift, mfsr_float2* outShift, int inPitch, int outPitch,
@@ -703,7 +718,8 @@ __global__ void __launch_bounds__(TRK_THREADS)
                       const float2* __restrict__ preShift, int preShiftPitch, float2* __restrict__ coordinates,
                       int coordinatesPitch, int imgWidth, int imgHeight, int imgPitch, int maxShift, int tileSize,
                       int tileCountX, int tileCountY, float threshold, const float* __restrict__ refSq, int tilesPerWg,
-                      const mfsr_prealign* __restrict__ base, float baseInvScale)
+                      const mfsr_prealign* __restrict__ base, float baseInvScale, const float2* __restrict__ coarse, int coarsePitch,
+                      int4 up, int upOldTile)
 {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int T = tileSize, S = maxShift, L = T + 2 * S, R = 2 * S + 1;
@@ -735,8 +751,11 @@ __global__ void __launch_bounds__(TRK_THREADS)
     for (int sl = 0; sl < tilesPerWg; sl++) {
         const int tileIdx = min(tile0 + sl, tileCount - 1);
         const int tileIdxY = tileIdx / tileCountX, tileIdxX = tileIdx - tileIdxY * tileCountX;
+        // pre-shift of the tile: given (B8's output), or taken here from the previous level's shifts (B8 folded in:
+        // up = {oldLevel, newLevel, oldCountX, oldCountY}), or none
         float2 pre = zero2;
         if (preShift) pre = row_ptr(preShift, preShiftPitch, tileIdxY)[tileIdxX];
+        else if (coarse) pre = upsample_shift_at(coarse, coarsePitch, up.x, up.y, up.z, up.w, upOldTile, T, tileIdxX, tileIdxY);
         float* sr = slot_ref(sl);
         float* sm = slot_mov(sl);
         for (int j0 = tid; j0 < nRef; j0 += 4 * TRK_THREADS) {
@@ -849,6 +868,7 @@ __global__ void __launch_bounds__(TRK_THREADS)
             const int tileIdxY = tileIdx / tileCountX, tileIdxX = tileIdx - tileIdxY * tileCountX;
             float2 pre = zero2;
             if (preShift) pre = row_ptr(preShift, preShiftPitch, tileIdxY)[tileIdxX];
+            else if (coarse) pre = upsample_shift_at(coarse, coarsePitch, up.x, up.y, up.z, up.w, upOldTile, T, tileIdxX, tileIdxY);
             float2 coord = subpixel_minimum(slot_dist(sl), S, minVal, minIdx, maxVal, threshold);
             coord.x = roundf(pre.x) + coord.x;
             coord.y = roundf(pre.y) + coord.y;
@@ -891,11 +911,11 @@ extern "C" int mfsr_tileSquaredSums(const float* refImg, float* outValues, int i
     return mfsr_launch_status("tileSquaredSums");
 }
 
-extern "C" int mfsr_trackTilesFusedBase(const float* refImg, const float* movedImg, const mfsr_float2* preShift,
-                                        int preShiftPitch, mfsr_float2* coordinates, int coordinatesPitch, int imgWidth,
-                                        int imgHeight, int imgPitch, int maxShift, int tileSize, int tileCountX,
-                                        int tileCountY, float threshold, const float* refSquaredSums,
-                                        const mfsr_prealign* base, float baseInvScale, mfsr_stream_t stream)
+static int track_tiles_fused_impl(const float* refImg, const float* movedImg, const mfsr_float2* preShift, int preShiftPitch,
+                                  mfsr_float2* coordinates, int coordinatesPitch, int imgWidth, int imgHeight, int imgPitch,
+                                  int maxShift, int tileSize, int tileCountX, int tileCountY, float threshold,
+                                  const float* refSquaredSums, const mfsr_prealign* base, float baseInvScale,
+                                  const mfsr_float2* coarse, int coarsePitch, int4 up, int upOldTile, mfsr_stream_t stream)
 {
     MFSR_REQUIRE(refImg && movedImg && coordinates && imgWidth > 0 && imgHeight > 0);
     MFSR_REQUIRE((long long)imgPitch >= 4LL * imgWidth && (imgPitch & 3) == 0);
@@ -921,7 +941,7 @@ extern "C" int mfsr_trackTilesFusedBase(const float* refImg, const float* movedI
     hipLaunchKernelGGL(k_trackTilesFused<N>, dim3(mfsr_cdiv(tiles, tilesPerWg)), dim3(TRK_THREADS), lds, mfsr_s(stream),  \
                        refImg, movedImg, (const float2*)preShift, preShiftPitch, (float2*)coordinates, coordinatesPitch, \
                        imgWidth, imgHeight, imgPitch, maxShift, tileSize, tileCountX, tileCountY, threshold,           \
-                       refSquaredSums, tilesPerWg, base, baseInvScale)
+                       refSquaredSums, tilesPerWg, base, baseInvScale, (const float2*)coarse, coarsePitch, up, upOldTile)
     if (nsx == 1)
         TRK_LAUNCH(1);
     else if (nsx == 2)
@@ -930,6 +950,34 @@ extern "C" int mfsr_trackTilesFusedBase(const float* refImg, const float* movedI
         TRK_LAUNCH(3);
 #undef TRK_LAUNCH
     return mfsr_launch_status("trackTilesFused");
+}
+
+extern "C" int mfsr_trackTilesFusedBase(const float* refImg, const float* movedImg, const mfsr_float2* preShift,
+                                        int preShiftPitch, mfsr_float2* coordinates, int coordinatesPitch, int imgWidth,
+                                        int imgHeight, int imgPitch, int maxShift, int tileSize, int tileCountX,
+                                        int tileCountY, float threshold, const float* refSquaredSums,
+                                        const mfsr_prealign* base, float baseInvScale, mfsr_stream_t stream)
+{
+    return track_tiles_fused_impl(refImg, movedImg, preShift, preShiftPitch, coordinates, coordinatesPitch, imgWidth, imgHeight,
+                                  imgPitch, maxShift, tileSize, tileCountX, tileCountY, threshold, refSquaredSums, base, baseInvScale,
+                                  nullptr, 0, make_int4(0, 0, 0, 0), 0, stream);
+}
+
+// the same with UpSampleShifts (B8, kernel.cu:642) folded in: the pre-shift of every tile is the bilinear up-sampling of the
+// previous (coarser) level's shifts `coarseShifts` (oldCountX x oldCountY tiles of oldTileSize at factor oldLevel), taken
+// inside the kernel with B8's own arithmetic -- one launch and one buffer less per level, same bits
+extern "C" int mfsr_trackTilesFusedUp(const float* refImg, const float* movedImg, const mfsr_float2* coarseShifts, int coarsePitch,
+                                      int oldLevel, int newLevel, int oldCountX, int oldCountY, int oldTileSize,
+                                      mfsr_float2* coordinates, int coordinatesPitch, int imgWidth, int imgHeight, int imgPitch,
+                                      int maxShift, int tileSize, int tileCountX, int tileCountY, float threshold,
+                                      const float* refSquaredSums, const mfsr_prealign* base, float baseInvScale,
+                                      mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(coarseShifts && oldLevel > 0 && newLevel > 0 && oldCountX > 0 && oldCountY > 0 && oldTileSize > 0);
+    MFSR_REQUIRE((long long)coarsePitch >= 8LL * oldCountX && (coarsePitch & 7) == 0 && ((uintptr_t)coarseShifts & 7) == 0);
+    return track_tiles_fused_impl(refImg, movedImg, nullptr, 0, coordinates, coordinatesPitch, imgWidth, imgHeight, imgPitch, maxShift,
+                                  tileSize, tileCountX, tileCountY, threshold, refSquaredSums, base, baseInvScale, coarseShifts,
+                                  coarsePitch, make_int4(oldLevel, newLevel, oldCountX, oldCountY), oldTileSize, stream);
 }
 
 extern "C" int mfsr_trackTilesFused(const float* refImg, const float* movedImg, const mfsr_float2* preShift,

@@ -501,6 +501,28 @@ def test_UpSampleShifts(orc, hip):
     assert_bitexact(o, h, "UpSampleShifts")
 
 
+@pytest.mark.parametrize("oldL,newL,oldT,T,S", [(4, 2, 16, 16, 3), (2, 1, 16, 32, 4), (4, 1, 32, 32, 8)])
+def test_trackTilesFusedUp_equals_UpSampleShifts_then_tracker(orc, hip, oldL, newL, oldT, T, S):
+    """B8 folded into the tracker: same bits as oracle UpSampleShifts (kernel.cu:642) followed by the fused tracker."""
+    W, H = 192, 128
+    tcx, tcy = W // T, H // T
+    ocx, ocy = (W * newL // oldL) // oldT, (H * newL // oldL) // oldT
+    r = rng(77)
+    base = r.random((H + 16, W + 16), dtype=np.float32)
+    ref = np.ascontiguousarray(base[8:8 + H, 8:8 + W])
+    mov = np.ascontiguousarray(base[7:7 + H, 10:10 + W])
+    coarse = r.uniform(-2.5, 2.5, (ocy, ocx, 2)).astype(np.float32)
+    pre = np.zeros((tcy, tcx, 2), np.float32)
+    orc.call("UpSampleShifts", coarse, pre, pitch_of(coarse), pitch_of(pre), oldL, newL, ocx, ocy, tcx, tcy, oldT, T)
+    want = np.zeros((tcy, tcx, 2), np.float32)
+    hip.call("trackTilesFused", ref, mov, pre, pitch_of(pre), want, pitch_of(want), W, H, pitch_of(ref), S, T, tcx, tcy, 0.0, None)
+    got = np.zeros((tcy, tcx, 2), np.float32)
+    hip.call("trackTilesFusedUp", ref, mov, coarse, pitch_of(coarse), oldL, newL, ocx, ocy, oldT, got, pitch_of(got), W, H,
+             pitch_of(ref), S, T, tcx, tcy, 0.0, None, None, 1.0)
+    assert_bitexact(want, got, "trackTilesFusedUp")
+    assert np.abs(want).max() > 0
+
+
 @pytest.mark.parametrize("T,S", [(16, 3), (32, 4), (32, 8)])
 def test_trackTilesFused_equals_chain(orc, hip, T, S):
     """Fused tracker == oracle chain B1,B2,cc,B3,B4x,B4y,B6,B7 + rounded pre-shift add, bit for bit."""
