@@ -282,8 +282,12 @@ __global__ void __launch_bounds__(256) k_crossCorrelateTiles(const float* __rest
     if (sy >= -S && sy <= S && sx >= -S && sx <= S) {
         const float* rt = refTiles + (size_t)tile * L * L;
         const float* mt = movedTiles + (size_t)tile * L * L;
-        for (int y = 0; y < tileSize; y++)
-            for (int x = 0; x < tileSize; x++) s += rt[(S + y) * L + (S + x)] * mt[(S + y + sy) * L + (S + x + sx)];
+        // row sums left to right, then the rows top to bottom (the order oracle/glue.c defines)
+        for (int y = 0; y < tileSize; y++) {
+            float row = 0;
+            for (int x = 0; x < tileSize; x++) row += rt[(S + y) * L + (S + x)] * mt[(S + y + sy) * L + (S + x + sx)];
+            s += row;
+        }
     }
     ccImage[(size_t)tile * L * L + i] = s;
 }

@@ -165,9 +165,9 @@ extern "C" int mfsr_normalizedCC(const float* ccImage, const float* squaredTempl
 // ---- B1/B2: convertToTilesOverlapBorder / PreShift (kernel.cu:265-378) ---------
 // source pixel of tile-local (pxX,pxY): base shift + rotation about the image
 // centre, roundf, float clamp (:299-313 / :358-372)
-__device__ __forceinline__ float tile_fetch_cs(const float* __restrict__ inImg, int imgWidth, int imgHeight, int imgPitch,
-                                               int tileSize, int tileIdxX, int tileIdxY, int pxX, int pxY, float2 shift,
-                                               float2 baseShift, float cf, float sf)
+// the whole-pixel offset every pixel of a tile is gathered at (the same for all its pixels)
+__device__ __forceinline__ int2 tile_shift_cs(int imgWidth, int imgHeight, int tileSize, int tileIdxX, int tileIdxY, float2 shift,
+                                              float2 baseShift, float cf, float sf)
 {
     shift.x += cf * -baseShift.x - sf * -baseShift.y;
     shift.y += sf * -baseShift.x + cf * -baseShift.y;
@@ -175,11 +175,26 @@ __device__ __forceinline__ float tile_fetch_cs(const float* __restrict__ inImg, 
     const float patchCenterY = (float)(tileIdxY * tileSize + tileSize / 2 - imgHeight / 2);
     shift.x += cf * patchCenterX - sf * patchCenterY - patchCenterX;
     shift.y += sf * patchCenterX + cf * patchCenterY - patchCenterY;
-    int pxInImgX = tileIdxX * tileSize + pxX + round2i(shift.x);
-    int pxInImgY = tileIdxY * tileSize + pxY + round2i(shift.y);
+    return make_int2(round2i(shift.x), round2i(shift.y));
+}
+
+// pixel (pxX, pxY) of the tile whose origin + whole-pixel offset is (originX, originY), clamped to the image
+__device__ __forceinline__ float tile_fetch_at(const float* __restrict__ inImg, int imgWidth, int imgHeight, int imgPitch, int originX,
+                                               int originY, int pxX, int pxY)
+{
+    int pxInImgX = originX + pxX;
+    int pxInImgY = originY + pxY;
     pxInImgX = f2i(fminf(fmaxf((float)pxInImgX, 0.0f), (float)(imgWidth - 1)));
     pxInImgY = f2i(fminf(fmaxf((float)pxInImgY, 0.0f), (float)(imgHeight - 1)));
     return row_ptr(inImg, imgPitch, pxInImgY)[pxInImgX];
+}
+
+__device__ __forceinline__ float tile_fetch_cs(const float* __restrict__ inImg, int imgWidth, int imgHeight, int imgPitch,
+                                               int tileSize, int tileIdxX, int tileIdxY, int pxX, int pxY, float2 shift,
+                                               float2 baseShift, float cf, float sf)
+{
+    const int2 o = tile_shift_cs(imgWidth, imgHeight, tileSize, tileIdxX, tileIdxY, shift, baseShift, cf, sf);
+    return tile_fetch_at(inImg, imgWidth, imgHeight, imgPitch, tileIdxX * tileSize + o.x, tileIdxY * tileSize + o.y, pxX, pxY);
 }
 
 __device__ __forceinline__ float tile_fetch(const float* __restrict__ inImg, int imgWidth, int imgHeight, int imgPitch,
@@ -696,8 +711,8 @@ extern "C" int mfsr_fftshift(mfsr_float2* fft, int width, int height, mfsr_strea
 // tile into LDS (same source-pixel rule as B1/B2, base shift/rotation = 0) and evaluate the
 // L2 distance of every candidate shift (sx, sy) in [0, 2S]^2:
 //     D = sum(ref^2) + sum_window(moved^2) - 2*sum(ref*moved)
-// with every sum taken in the order the unfused chain uses (row-major serial for sum(ref^2)
-// and the correlation; per-row sums then the sum of rows for the box term), so D is
+// with every sum taken in the order the unfused chain uses (row-major serial for sum(ref^2);
+// per-row sums then the sum of rows for the correlation and the box term), so D is
 // bit-identical to squaredSum'(serial)/boxFilter/normalizedCC fed by the direct correlation.
 //  * sum(ref^2) does not depend on the candidate or on the moved frame: it is taken once per
 //    reference (mfsr_tileSquaredSums) and passed in; without it one lane per tile takes it here.
@@ -823,6 +838,9 @@ __global__ void __launch_bounds__(TRK_THREADS)
             for (int y = 0; y < T; y++) {
                 const float* rrow = ref + y * T;
                 const float* mrow = mov + y * Lp;
+                float rs[TRK_NSX];  // row sum, left to right; the rows add top to bottom
+#pragma unroll
+                for (int j = 0; j < TRK_NSX; j++) rs[j] = 0;
                 int x = 0;
                 for (; x + 8 <= T; x += 8) {
                     float r[8], m[8 + TRK_NSX - 1];
@@ -833,13 +851,15 @@ __global__ void __launch_bounds__(TRK_THREADS)
 #pragma unroll
                     for (int d = 0; d < 8; d++)
 #pragma unroll
-                        for (int j = 0; j < TRK_NSX; j++) cc[j] += r[d] * m[d + j];
+                        for (int j = 0; j < TRK_NSX; j++) rs[j] += r[d] * m[d + j];
                 }
                 for (; x < T; x++) {
                     const float r = rrow[x];
 #pragma unroll
-                    for (int j = 0; j < TRK_NSX; j++) cc[j] += r * mrow[x + j];
+                    for (int j = 0; j < TRK_NSX; j++) rs[j] += r * mrow[x + j];
                 }
+#pragma unroll
+                for (int j = 0; j < TRK_NSX; j++) cc[j] += rs[j];
             }
             const float sq = *slot_sq(sl);
             const float* rows = slot_row(sl);
@@ -870,6 +890,206 @@ __global__ void __launch_bounds__(TRK_THREADS)
             if (preShift) pre = row_ptr(preShift, preShiftPitch, tileIdxY)[tileIdxX];
             else if (coarse) pre = upsample_shift_at(coarse, coarsePitch, up.x, up.y, up.z, up.w, upOldTile, T, tileIdxX, tileIdxY);
             float2 coord = subpixel_minimum(slot_dist(sl), S, minVal, minIdx, maxVal, threshold);
+            coord.x = roundf(pre.x) + coord.x;
+            coord.y = roundf(pre.y) + coord.y;
+            row_ptr(coordinates, coordinatesPitch, tileIdxY)[tileIdxX] = coord;
+        }
+    }
+}
+
+// ---- fused tracker, compile-time tile geometry (the pipeline's sizes) -----------------------------
+// The kernel above gives every candidate shift to one thread: (2S+1)^2 chains of T*T dependent multiply-adds per tile,
+// 81 of 128 lanes busy, about one wavefront per SIMD at 4K and two LDS reads per multiply-add -- 37 us per launch with
+// the VALUs 45 % busy.  The correlation's summation order (row sums, then the rows; oracle/glue.c) leaves T*(2S+1)^2
+// independent row sums per tile, which this kernel spreads differently:
+//   * correlation item = (template row y, sy): the thread loads the template row (T floats) and the patch row y + sy
+//     (T + 2S floats) ONCE with ds_read_b128 and forms the 2S+1 row sums of all sx from registers -- 2S+1 independent
+//     chains per thread, (2T + 2S) / (T * (2S+1)) LDS floats per multiply-add instead of 2;
+//   * TPW tiles share a workgroup so that the TPW*T*(2S+1) items fill whole wavefronts; one more wavefront takes the
+//     box term's row sums (a patch row per lane, all sx from registers) at the same time;
+//   * LDS row strides are 4 * odd, so the 16 lanes of a ds_read_b128 quarter, which read 16 different rows, touch 16
+//     different bank groups; row sums land in rowcc[item * R + sx] (stride R, odd: conflict-free).
+// Then (2S+1)^2 threads per tile add the T row sums top to bottom (+ the box rows), and one wavefront per tile takes
+// min / argmin / max and the sub-pixel fit as above.  Same bits as the kernel above for every input.
+constexpr int trk_odd4(int n)
+{
+    int q = (n + 3) / 4;
+    if ((q & 1) == 0) q++;
+    return 4 * q;
+}
+
+template <int T, int S, int TPW>
+struct TrkFast {
+    static constexpr int L = T + 2 * S, R = 2 * S + 1;
+    static constexpr int Tp = trk_odd4(T), Lp = trk_odd4(L);
+    static constexpr int nRef = T * Tp, nMov = L * Lp, nRowSq = L * R, nRowCc = T * R * R, nDist = R * R;
+    static constexpr int slotFloats = (nRef + nMov + nRowSq + nRowCc + nDist + 4 + 3) & ~3;
+    static constexpr int items = TPW * T * R;                   // correlation items per workgroup
+    static constexpr int corrThreads = (items + 63) & ~63;
+    static constexpr int threads = corrThreads + 64;            // + the box-term wavefront
+    static constexpr size_t ldsBytes = sizeof(float) * (size_t)slotFloats * TPW;
+    static_assert(threads <= 1024 && ldsBytes <= 64 * 1024 && TPW * R * R <= corrThreads && T % 4 == 0, "tile geometry");
+};
+
+template <int T, int S, int TPW>
+__global__ void __launch_bounds__((TrkFast<T, S, TPW>::threads))
+    k_trackTilesFast(const float* __restrict__ refImg, const float* __restrict__ movedImg, const float2* __restrict__ preShift,
+                     int preShiftPitch, float2* __restrict__ coordinates, int coordinatesPitch, int imgWidth, int imgHeight,
+                     int imgPitch, int tileCountX, int tileCountY, float threshold, const float* __restrict__ refSq,
+                     const mfsr_prealign* __restrict__ base, float baseInvScale, const float2* __restrict__ coarse, int coarsePitch,
+                     int4 up, int upOldTile)
+{
+    using G = TrkFast<T, S, TPW>;
+    constexpr int L = G::L, R = G::R, Tp = G::Tp, Lp = G::Lp;
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const int tid = threadIdx.x;
+    const int tileCount = tileCountX * tileCountY;
+    const int tile0 = blockIdx.x * TPW;
+    const float2 zero2 = make_float2(0.0f, 0.0f);
+    float2 baseShift = zero2;
+    float baseCos = 1.0f, baseSin = 0.0f;
+    if (base) {
+        baseShift = make_float2(base->shiftX * baseInvScale, base->shiftY * baseInvScale);
+        baseCos = base->cosRotation;
+        baseSin = base->sinRotation;
+    }
+    auto slot_ref = [&](int s) { return s_mem + s * G::slotFloats; };
+    auto slot_mov = [&](int s) { return s_mem + s * G::slotFloats + G::nRef; };
+    auto slot_rowsq = [&](int s) { return s_mem + s * G::slotFloats + G::nRef + G::nMov; };
+    auto slot_rowcc = [&](int s) { return s_mem + s * G::slotFloats + G::nRef + G::nMov + G::nRowSq; };
+    auto slot_dist = [&](int s) { return s_mem + s * G::slotFloats + G::nRef + G::nMov + G::nRowSq + G::nRowCc; };
+    auto pre_of = [&](int tileIdxX, int tileIdxY) {
+        float2 pre = zero2;
+        if (preShift) pre = row_ptr(preShift, preShiftPitch, tileIdxY)[tileIdxX];
+        else if (coarse) pre = upsample_shift_at(coarse, coarsePitch, up.x, up.y, up.z, up.w, upOldTile, T, tileIdxX, tileIdxY);
+        return pre;
+    };
+
+    // gather, with every load of a phase in flight at once (the kernel is bound by these latencies, not by arithmetic):
+    //   1. template (B1: zero shift, the clamped tile itself) -> registers
+    //   2. meanwhile one lane per tile slot takes the pre-shift (given, or B8 folded in) and the patch origin -> LDS
+    //   3. pre-shifted patch (B2) -> registers; 4. both -> LDS
+    constexpr int nRefAll = TPW * T * T, nMovAll = TPW * L * L;
+    constexpr int NR = (nRefAll + G::threads - 1) / G::threads, NM = (nMovAll + G::threads - 1) / G::threads;
+    __shared__ int2 s_origin[TPW];
+    __shared__ float2 s_pre[TPW];
+    float vr[NR], vm[NM];
+#pragma unroll
+    for (int u = 0; u < NR; u++) {
+        const int j = min(tid + u * G::threads, nRefAll - 1);
+        const int sl = j / (T * T), q = j - sl * (T * T), y = q / T, x = q - y * T;
+        const int tileIdx = min(tile0 + sl, tileCount - 1);  // slots past the end re-read the last tile, never written back
+        const int tileIdxY = tileIdx / tileCountX, tileIdxX = tileIdx - tileIdxY * tileCountX;
+        vr[u] = tile_fetch_at(refImg, imgWidth, imgHeight, imgPitch, tileIdxX * T + S, tileIdxY * T + S, x, y);
+    }
+    if (tid < TPW) {
+        const int tileIdx = min(tile0 + tid, tileCount - 1);
+        const int tileIdxY = tileIdx / tileCountX, tileIdxX = tileIdx - tileIdxY * tileCountX;
+        const float2 pre = pre_of(tileIdxX, tileIdxY);
+        const int2 o = tile_shift_cs(imgWidth, imgHeight, T, tileIdxX, tileIdxY, pre, baseShift, baseCos, baseSin);
+        s_origin[tid] = make_int2(tileIdxX * T + o.x, tileIdxY * T + o.y);
+        s_pre[tid] = pre;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NM; u++) {
+        const int k = min(tid + u * G::threads, nMovAll - 1);
+        const int sl = k / (L * L), q = k - sl * (L * L), y = q / L, x = q - y * L;
+        const int2 o = s_origin[sl];
+        vm[u] = tile_fetch_at(movedImg, imgWidth, imgHeight, imgPitch, o.x, o.y, x, y);
+    }
+#pragma unroll
+    for (int u = 0; u < NR; u++) {
+        const int j = tid + u * G::threads;
+        if (j < nRefAll) {
+            const int sl = j / (T * T), q = j - sl * (T * T), y = q / T, x = q - y * T;
+            slot_ref(sl)[y * Tp + x] = vr[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NM; u++) {
+        const int k = tid + u * G::threads;
+        if (k < nMovAll) {
+            const int sl = k / (L * L), q = k - sl * (L * L), y = q / L, x = q - y * L;
+            slot_mov(sl)[y * Lp + x] = vm[u];
+        }
+    }
+    __syncthreads();
+
+    if (tid < G::items) {
+        // correlation row sums of (tile slot, template row y, sy), all sx
+        const int sl = tid / (T * R), q = tid - sl * (T * R), y = q / R, sy = q - y * R;
+        const float4* rrow = (const float4*)(slot_ref(sl) + y * Tp);
+        const float4* mrow = (const float4*)(slot_mov(sl) + (y + sy) * Lp);
+        float m[(L + 3) & ~3];
+#pragma unroll
+        for (int d = 0; d < (L + 3) / 4; d++) {
+            const float4 t = mrow[d];
+            m[4 * d] = t.x, m[4 * d + 1] = t.y, m[4 * d + 2] = t.z, m[4 * d + 3] = t.w;
+        }
+        float acc[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) acc[j] = 0;
+#pragma unroll
+        for (int x4 = 0; x4 < T; x4 += 4) {
+            const float4 t = rrow[x4 / 4];
+            const float r[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+#pragma unroll
+                for (int j = 0; j < R; j++) acc[j] += r[d] * m[x4 + d + j];
+        }
+        float* out = slot_rowcc(sl) + q * R;
+#pragma unroll
+        for (int j = 0; j < R; j++) out[j] = acc[j];
+    } else if (tid >= G::corrThreads) {
+        // box term: row sums of moved^2 (serial over x, as boxFilterWithBorderX), a patch row per lane
+        for (int i = tid - G::corrThreads; i < TPW * L; i += 64) {
+            const int sl = i / L, ry = i - sl * L;
+            const float4* mrow = (const float4*)(slot_mov(sl) + ry * Lp);
+            float m2[(L + 3) & ~3];
+#pragma unroll
+            for (int d = 0; d < (L + 3) / 4; d++) {
+                const float4 t = mrow[d];
+                m2[4 * d] = t.x * t.x, m2[4 * d + 1] = t.y * t.y, m2[4 * d + 2] = t.z * t.z, m2[4 * d + 3] = t.w * t.w;
+            }
+            float* out = slot_rowsq(sl) + ry * R;
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                float a = 0;
+#pragma unroll
+                for (int x = 0; x < T; x++) a += m2[j + x];
+                out[j] = a;
+            }
+        }
+    }
+    __syncthreads();
+
+    // candidate (tile slot, sy, sx): rows top to bottom, box term, distance
+    if (tid < TPW * R * R) {
+        const int sl = tid / (R * R), cand = tid - sl * (R * R), sy = cand / R, sx = cand - sy * R;
+        const float* rc = slot_rowcc(sl) + cand;
+        const float* rq = slot_rowsq(sl) + sy * R + sx;
+        float cc = 0, box = 0;
+#pragma unroll 8
+        for (int y = 0; y < T; y++) cc += rc[y * R * R];
+#pragma unroll 8
+        for (int y = 0; y < T; y++) box += rq[y * R];
+        const float sq = refSq[min(tile0 + sl, tileCount - 1)];
+        slot_dist(sl)[cand] = sq + box - 2 * cc;
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave < TPW && tile0 + wave < tileCount) {
+        const int tileIdx = tile0 + wave;
+        float minVal, maxVal;
+        int minIdx;
+        wave_min_argmin_max(slot_dist(wave), R * R, lane, minVal, minIdx, maxVal);
+        if (lane == 0) {
+            const int tileIdxY = tileIdx / tileCountX, tileIdxX = tileIdx - tileIdxY * tileCountX;
+            const float2 pre = s_pre[wave];
+            float2 coord = subpixel_minimum(slot_dist(wave), S, minVal, minIdx, maxVal, threshold);
             coord.x = roundf(pre.x) + coord.x;
             coord.y = roundf(pre.y) + coord.y;
             row_ptr(coordinates, coordinatesPitch, tileIdxY)[tileIdxX] = coord;
@@ -924,6 +1144,25 @@ static int track_tiles_fused_impl(const float* refImg, const float* movedImg, co
                  ((uintptr_t)coordinates & 7) == 0);
     if (preShift)
         MFSR_REQUIRE((long long)preShiftPitch >= 8LL * tileCountX && (preShiftPitch & 7) == 0 && ((uintptr_t)preShift & 7) == 0);
+    // the pipeline's tile sizes run the compile-time kernel (sum(ref^2) given, as the pipeline does); MFSR_TRK_FAST=0: A/B
+    static const bool fast = [] {
+        const char* e = getenv("MFSR_TRK_FAST");
+        return !(e && e[0] == '0');
+    }();
+#define TRK_FAST_CASE(TT, SS, TPW)                                                                                       \
+    if (fast && refSquaredSums && tileSize == TT && maxShift == SS) {                                                    \
+        using G = TrkFast<TT, SS, TPW>;                                                                                  \
+        hipLaunchKernelGGL((k_trackTilesFast<TT, SS, TPW>), dim3(mfsr_cdiv(tileCountX * tileCountY, TPW)), dim3(G::threads), \
+                           G::ldsBytes, mfsr_s(stream), refImg, movedImg, (const float2*)preShift, preShiftPitch,         \
+                           (float2*)coordinates, coordinatesPitch, imgWidth, imgHeight, imgPitch, tileCountX, tileCountY,  \
+                           threshold, refSquaredSums, base, baseInvScale, (const float2*)coarse, coarsePitch, up, upOldTile); \
+        return mfsr_launch_status("trackTilesFast");                                                                     \
+    }
+    TRK_FAST_CASE(32, 4, 2)
+    TRK_FAST_CASE(16, 3, 4)
+    TRK_FAST_CASE(16, 4, 4)
+    TRK_FAST_CASE(32, 8, 1)
+#undef TRK_FAST_CASE
     static const int nsx = [] {
         const char* e = getenv("MFSR_TRK_NSX");
         return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 1;

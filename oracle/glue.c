@@ -197,7 +197,11 @@ void orc_downsample2x(const float* in, int inPitch, float* out, int outPitch, in
  * (kernel.cu:484-501 is the only part of it in the reference).  Output has
  * the FFT's wrapped layout that normalizedCC reads (kernel.cu:248-254):
  * cc[tile][sy mod L][sx mod L] = sum_{y,x in TxT} ref[S+y][S+x] *
- * moved[S+y+sy][S+x+sx] for sx,sy in [-S,S]; all other entries 0. */
+ * moved[S+y+sy][S+x+sx] for sx,sy in [-S,S]; all other entries 0.
+ * Summation order (the build's choice -- the FFT fixes none): per tile row the
+ * products are added left to right, then the row sums top to bottom -- the
+ * order boxFilterWithBorderX / Y (kernel.cu:150-227) give the box term of the
+ * same distance, and one that leaves T x (2S+1)^2 independent row sums per tile. */
 void orc_crossCorrelateTiles(const float* refTiles, const float* movedTiles, float* ccImage, int maxShift, int tileSize,
                              int tileCount)
 {
@@ -212,8 +216,11 @@ void orc_crossCorrelateTiles(const float* refTiles, const float* movedTiles, flo
         for (int sy = -S; sy <= S; sy++)
             for (int sx = -S; sx <= S; sx++) {
                 float s = 0;
-                for (int y = 0; y < tileSize; y++)
-                    for (int x = 0; x < tileSize; x++) s += rt[(S + y) * L + (S + x)] * mt[(S + y + sy) * L + (S + x + sx)];
+                for (int y = 0; y < tileSize; y++) {
+                    float row = 0;
+                    for (int x = 0; x < tileSize; x++) row += rt[(S + y) * L + (S + x)] * mt[(S + y + sy) * L + (S + x + sx)];
+                    s += row;
+                }
                 int fy = sy < 0 ? L + sy : sy;
                 int fx = sx < 0 ? L + sx : sx;
                 cc[fy * L + fx] = s;

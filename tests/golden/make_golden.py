@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
-"""Regenerates tests/golden/golden_v1.npz from the CPU oracle.
+"""Regenerates tests/golden/golden_v2.npz from the CPU oracle.
 
 The reference ships no expected outputs for this path, so these
 fixtures are NOT reference outputs: they are seeded inputs plus the outputs of this
 repository's oracle (oracle/*.c, a restatement of the reference kernels), frozen so that
 (a) the oracle cannot drift silently between rounds and (b) the GPU path can be checked on
 a box without rebuilding anything.  Run from the repo root:  python tests/golden/make_golden.py
+
+v2 (round 2): the direct tile correlation -- the build's stand-in for the reference's FFT chain, whose
+summation order nothing in the reference fixes -- now adds the products row by row and then the row sums
+(oracle/glue.c orc_crossCorrelateTiles); tile_dist / tile_coord moved by fp32 rounding (<= 1.4e-4 of 54,
+2e-6 px), every other array is bit-identical to v1.
 """
 import ctypes
 import os
@@ -104,6 +109,6 @@ def build():
 
 if __name__ == "__main__":
     g = build()
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_v1.npz")
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_v2.npz")
     np.savez_compressed(out, **g)
     print("wrote", out, os.path.getsize(out), "bytes,", len(g), "arrays")

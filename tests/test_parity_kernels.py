@@ -504,7 +504,7 @@ def test_UpSampleShifts(orc, hip):
 @pytest.mark.parametrize("oldL,newL,oldT,T,S", [(4, 2, 16, 16, 3), (2, 1, 16, 32, 4), (4, 1, 32, 32, 8)])
 def test_trackTilesFusedUp_equals_UpSampleShifts_then_tracker(orc, hip, oldL, newL, oldT, T, S):
     """B8 folded into the tracker: same bits as oracle UpSampleShifts (kernel.cu:642) followed by the fused tracker."""
-    W, H = 192, 128
+    W, H = 224, 160  # 7 x 5 tiles of 32: the last workgroup of the compile-time kernel (2 tiles each) is half empty
     tcx, tcy = W // T, H // T
     ocx, ocy = (W * newL // oldL) // oldT, (H * newL // oldL) // oldT
     r = rng(77)
@@ -521,6 +521,14 @@ def test_trackTilesFusedUp_equals_UpSampleShifts_then_tracker(orc, hip, oldL, ne
              pitch_of(ref), S, T, tcx, tcy, 0.0, None, None, 1.0)
     assert_bitexact(want, got, "trackTilesFusedUp")
     assert np.abs(want).max() > 0
+    # with sum(ref^2) handed in (what the pipeline does) these tile sizes run the compile-time kernel: same bits,
+    # also with a base shift (global pre-alignment without rotation: cos = 1, sin = 0 exactly)
+    sq = np.zeros(tcx * tcy, np.float32)
+    hip.call("tileSquaredSums", ref, sq, W, H, pitch_of(ref), S, T, tcx, tcy)
+    got2 = np.zeros((tcy, tcx, 2), np.float32)
+    hip.call("trackTilesFusedUp", ref, mov, coarse, pitch_of(coarse), oldL, newL, ocx, ocy, oldT, got2, pitch_of(got2), W, H,
+             pitch_of(ref), S, T, tcx, tcy, 0.0, sq, None, 1.0)
+    assert_bitexact(want, got2, "trackTilesFusedUp(refSquaredSums)")
 
 
 @pytest.mark.parametrize("T,S", [(16, 3), (32, 4), (32, 8)])
@@ -562,6 +570,25 @@ def test_trackTilesFused_equals_chain(orc, hip, T, S):
     got2 = np.zeros((tcy, tcx, 2), np.float32)
     hip.call("trackTilesFused", ref, mov, pre, pitch_of(pre), got2, pitch_of(got2), W, H, pitch_of(ref), S, T, tcx, tcy, 0.0, sq2)
     assert_bitexact(coord, got2, "trackTilesFused(refSquaredSums)")
+    # global pre-alignment without rotation (B2's baseShift, kernel.cu:358-368; cos = 1 and sin = 0 exactly), read by the
+    # kernel from a device mfsr_prealign: same bits as the oracle chain with that base shift -- both kernels
+    bs = F2([3.0, -2.0])
+    orc.call("convertToTilesOverlapPreShift", mov, mt, pre, pitch_of(pre), W, H, pitch_of(mov), S, T, tcx, tcy, bs, 0.0)
+    orc.call("crossCorrelateTiles", rt, mt, cc, S, T, n)
+    orc.call("boxFilterWithBorderX", mt, bx, S, T, n)
+    orc.call("boxFilterWithBorderY", bx, by, S, T, n)
+    orc.call("normalizedCC", cc, sq, by, dist, S, T, n)
+    coordB = np.zeros((tcy, tcx, 2), np.float32)
+    orc.call("findMinimum", dist, coordB, pitch_of(coordB), S, n, tcx, 0.0)
+    orc.call("addRoundedPreShift", pre, pitch_of(pre), coordB, pitch_of(coordB), tcx, tcy)
+    assert not np.array_equal(coordB, coord)
+    pa = np.zeros(12, np.float32)  # mfsr_prealign: shiftX, shiftY, rotation, cos, sin, 7 x int32
+    pa[:5] = [3.0, -2.0, 0.0, 1.0, 0.0]
+    for sqv, what in ((None, "generic"), (sq2, "compile-time")):
+        gotB = np.zeros((tcy, tcx, 2), np.float32)
+        hip.call("trackTilesFusedBase", ref, mov, pre, pitch_of(pre), gotB, pitch_of(gotB), W, H, pitch_of(ref), S, T, tcx, tcy,
+                 0.0, sqv, pa, 1.0)
+        assert_bitexact(coordB, gotB, f"trackTilesFusedBase({what})")
     # interior tiles whose residual (truth - round(pre)) lies strictly inside the search range
     # recover the true shift (-1, +2); on the border ring findMinimum returns 0 (kernel.cu:548-553)
     res = np.array([-1.0, 2.0]) - np.round(pre)
