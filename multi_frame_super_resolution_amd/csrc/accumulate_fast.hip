@@ -29,6 +29,7 @@
 #include <cstdlib>
 
 #include "accumulate_common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -200,10 +201,12 @@ __device__ __forceinline__ void tap_weights13(float kx, float ky, float kz, floa
 // (y parity << 1) | x parity of mask cell `cell` on tap row jt's mask row -- the certainty texels are staged in LDS in
 // CFA-position order, so "which channel does this site see" is an LDS ADDRESS (a few integer ops per pixel) instead of
 // three v_bitop3 selects per tap row and cell.
-template <int K, int CFA, bool PARITY = false, typename MaskF>
-__device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float kx, float ky, float kz,
-                                             const uint16_t* __restrict__ raw, int dimX, MaskF mval,
-                                             const StripLevels& lv, float* accP, float* accW)
+// strip_pixel_w: the pixel with its 13 tap weights given (they depend on the kernel parameters only, i.e. not on the
+// frame: a kernel that takes several frames per launch computes them once per pixel).
+// RawF: void rawf(int x0, int y0, float (&s)[3][3]) -> the 3x3 raw sites whose top left one is (x0, y0).
+template <int K, int CFA, bool PARITY = false, typename RawF, typename MaskF>
+__device__ __forceinline__ void strip_pixel_w(int X, int Y, int sx, int sy, const float (&w)[13], RawF rawf, MaskF mval,
+                                               const StripLevels& lv, float* accP, float* accW)
 {
     const int qx = X + sx - 2, qy = Y + sy - 2;
     const int x0 = qx >> 1, y0 = qy >> 1;
@@ -213,16 +216,8 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
     auto andm = [](uint32_t m, float a) { return __uint_as_float(m & __float_as_uint(a)); };
 
     float s[3][3];
-    {
-        const uint16_t* r = raw + (size_t)y0 * dimX + x0;
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-#pragma unroll
-            for (int i = 0; i < 3; i++) s[j][i] = (float)r[j * dimX + i];
-    }
+    rawf(x0, y0, s);
 
-    float w[13];
-    tap_weights13(kx, ky, kz, w);
     // tap columns 1 and 3: part that joins the lower / the upper site column
     float wl[13], wh[13];
 #pragma unroll
@@ -311,6 +306,23 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
     W[1][1] = Om[1][1];
 
     classes_to_channels<K, CFA>(S, W, mP, mQ, lv, accP, accW);
+}
+
+template <int K, int CFA, bool PARITY = false, typename MaskF>
+__device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float kx, float ky, float kz,
+                                             const uint16_t* __restrict__ raw, int dimX, MaskF mval,
+                                             const StripLevels& lv, float* accP, float* accW)
+{
+    float w[13];
+    tap_weights13(kx, ky, kz, w);
+    auto rawf = [&](int x0, int y0, float (&s)[3][3]) {
+        const uint16_t* r = raw + (size_t)y0 * dimX + x0;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) s[j][i] = (float)r[j * dimX + i];
+    };
+    strip_pixel_w<K, CFA, PARITY>(X, Y, sx, sy, w, rawf, mval, lv, accP, accW);
 }
 
 // Frame margin (HR pixels) that the strip/tile kernels leave to k_accumulateMargin: taps of
@@ -549,6 +561,10 @@ __global__ void __launch_bounds__(256)
 #define TILE_WAVES2 3
 #endif
 #define TILE_WAVES_NF(NF) ((NF) == 1 ? TILE_WAVES : TILE_WAVES2)
+// two frames per launch: pixel-major order with the tap weights shared by both frames (0: frame-major, weights per frame)
+#ifndef TILE_PIXEL_MAJOR
+#define TILE_PIXEL_MAJOR 1
+#endif
 // NF frames per launch (1 or 2).  Everything that does not depend on the frame is done once for
 // both: the accumulator staging and write-back (the 48 B/px/frame of HBM traffic become 24), the
 // kernel-parameter mix, the column/row fractions.  The two frames add into the same registers.
@@ -690,6 +706,77 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     for (int i = 0; i < 12; i++) accP[i] = accW[i] = 0.0f;
     const uint32_t xmax = (uint32_t)(2 * dimX - 5), ymax = (uint32_t)(2 * dimY - 5);
     uint32_t safeBits = 0;  // bit n: frame n took the fast path
+#if TILE_PIXEL_MAJOR
+    if constexpr (NF > 1) {
+        // Two frames, pixel-major: the 13 tap weights of a pixel (12 v_exp_f32 and their exponents: a fifth of the
+        // pixel's arithmetic) depend on the kernel parameters only, so each pixel takes them ONCE and applies them to
+        // both frames before the next pixel starts -- 13 live registers instead of the 4 x 13 a frame-major loop would
+        // have to keep (that was 214 VGPRs; recomputing them per frame was the faster frame-major form).
+        // Pass 1, per frame: whole-pixel flow of the four pixels (packed 16:16) and the fast-path admission.
+        uint32_t sxy[NF][4];
+#pragma unroll
+        for (int n = 0; n < NF; n++) {
+            float2 Ft[2][3];
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) Ft[r][c] = sF[n][fr_ + r][lx + c];
+            bool safe = geomOk && kOk;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ci = k < 2 ? 0 : 1;
+                const float ux = lerp4(Ft[0][ci].x, Ft[0][ci + 1].x, Ft[1][ci].x, Ft[1][ci + 1].x, av[k], b);
+                const float uy = lerp4(Ft[0][ci].y, Ft[0][ci + 1].y, Ft[1][ci].y, Ft[1][ci + 1].y, av[k], b);
+                const int sx = round2i(ux * 2.0f), sy = round2i(uy * 2.0f);
+                const int qx = X0 + k + sx - 2, qy = Y + sy - 2;
+                // as below, with the rounded flow inside 16 signed bits (wilder strips take the straight arithmetic)
+                safe = safe && (uint32_t)(sx + (1 << 15)) < (2u << 15) && (uint32_t)(sy + (1 << 15)) < (2u << 15) &&
+                       (uint32_t)qx <= xmax && (uint32_t)qy <= ymax;
+                sxy[n][k] = ((uint32_t)sx & 0xffffu) | ((uint32_t)sy << 16);
+            }
+            if (safe) safeBits |= 1u << n;
+        }
+        // Pass 2, per pixel: weights once, then frame after frame.  What the eight pixel-frame bodies share is taken
+        // here once (each body is its own divergent region, the compiler does not hoist across them): the LDS address of
+        // the certainty row each tap row reads, and the raw row bases (uniform: SGPR pairs, 32-bit lane offsets).
+        const float* mrow[5];
+#pragma unroll
+        for (int jt = 0; jt < 5; jt++) mrow[jt] = (const float*)&sM[0][((ly + jt - 2) >> 2) + 1][lx];
+        const char* rawRow[NF][3];
+#pragma unroll
+        for (int n = 0; n < NF; n++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) rawRow[n][j] = (const char*)(fr.f[n].raw + (size_t)j * dimX);
+        auto pixel = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (safeBits == 0) return;
+            float w[13];
+            tap_weights13(kxa[k], kya[k], kza[k], w);
+#pragma unroll
+            for (int n = 0; n < NF; n++) {
+                if ((safeBits >> n) & 1u) {
+                    auto rawf = [&](int x0, int y0, float (&sv)[3][3]) {
+                        const uint32_t boff = (uint32_t)(y0 * dimX + x0) * 2u;  // admitted strips: x0, y0 >= 0, inside the frame
+#pragma unroll
+                        for (int j = 0; j < 3; j++) {
+                            const char* rb = rawRow[n][j] + (size_t)boff;
+#pragma unroll
+                            for (int i = 0; i < 3; i++) sv[j][i] = (float)*(const uint16_t*)(rb + 2 * i);
+                        }
+                    };
+                    auto mval = [&](int jt, int cell, int e) { return mrow[jt][n * (3 * TILE_COLS * 4) + cell * 4 + e]; };
+                    const int sx = (int)(int16_t)(sxy[n][k] & 0xffffu), sy = (int)sxy[n][k] >> 16;
+                    strip_pixel_w<k, CFA, true>(X0 + k, Y, sx, sy, w, rawf, mval, lv, accP, accW);
+                }
+            }
+        };
+        pixel(std::integral_constant<int, 0>{});
+        pixel(std::integral_constant<int, 1>{});
+        pixel(std::integral_constant<int, 2>{});
+        pixel(std::integral_constant<int, 3>{});
+    } else
+#endif
+    {
     // one frame after the other in a real loop (not unrolled: the two bodies would only compete for
     // registers); the frame's pointers are picked with scalar selects so the argument struct stays
     // in SGPRs
@@ -748,6 +835,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
             strip_pixel<2, CFA, true>(X0 + 2, Y, sx[2], sy[2], kxa[2], kya[2], kza[2], raw, dimX, mval, lv, accP, accW);
             strip_pixel<3, CFA, true>(X0 + 3, Y, sx[3], sy[3], kxa[3], kya[3], kza[3], raw, dimX, mval, lv, accP, accW);
         }
+    }
     }
     float* myP = (float*)&sAcc[ly][0][0] + lx * 12;  // this lane's 4 pixels x 3 channels inside the staged segment
     float* myW = (float*)&sAcc[ly][1][0] + lx * 12;
