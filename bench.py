@@ -17,7 +17,7 @@ frames-per-GPU x N frames.
 Also reported on the same JSON line:
   end_to_end   : SURVEY.md 8(d)'s definition -- first H2D enqueue to D2H of the result complete, one burst in flight,
                  median of 20 (frames in pinned host memory through mfsr_burst_*_host);
-  roofline     : the warp+fuse launches (two frames per launch), HIP-event timed around every launch inside the timed
+  roofline     : the warp+fuse launches (a group of up to four frames per launch), HIP-event timed around every launch inside the timed
                  region; frac = bytes a launch MUST move / time / 8 TB/s; "bound": "valu" with the VALU-issue ceiling
                  from the PMC instruction count; traffic = PMC HBM bytes; reference_structure = SURVEY's per-frame RMW
                  accounting (what the reference's kernel would move), labelled as such;
@@ -64,7 +64,7 @@ def fuse_input_bytes_per_frame(W, H, s, mono):
 def fuse_bytes_reference_structure(W, H, s, mono):
     """SURVEY.md section 8(d)'s reference-structure figure for ONE frame: one launch per frame, both accumulator
     plane-sets read-modify-written in HBM (HR*48 B) + every input.  What the reference's kernel moves per frame; the
-    frame-paired kernel of this build moves the accumulators once per TWO frames, so this is NOT what it moves."""
+    frame-grouped kernel of this build moves the accumulators once per group of up to four frames, so this is NOT what it moves."""
     lr, hr = W * H, W * H * s * s
     trk = lr if mono else lr // 4
     return hr * 48 + fuse_input_bytes_per_frame(W, H, s, mono) + trk * 16
@@ -79,9 +79,10 @@ def fuse_bytes_must_move(W, H, s, mono, frames_in_launch, first_of_burst):
     return hr * (24 if first_of_burst else 48) + trk * 16 + frames_in_launch * fuse_input_bytes_per_frame(W, H, s, mono)
 
 
-def burst_fuse_bytes(W, H, s, mono, frames, pair):
-    """(launches, must-move bytes) of the warp+fuse launches of one burst of `frames` frames on one rank."""
-    per = 2 if pair else 1
+def burst_fuse_bytes(W, H, s, mono, frames, per):
+    """(launches, must-move bytes) of the warp+fuse launches of one burst of `frames` frames on one rank,
+    `per` frames per launch (mfsr_burst_group_size)."""
+    per = max(int(per), 1)
     launches, total, left, first = 0, 0, frames, True
     while left > 0:
         n = min(per, left)
@@ -164,6 +165,8 @@ def main():
                          "align+fuse of burst i+1")
     ap.add_argument("--force-pipelined", action="store_true", help="use the two-context pipelined step loop even at N=1 (test)")
     ap.add_argument("--no-pair", action="store_true", help="cfg.pairFrames = 0: one warp+fuse launch per frame (the reference's structure)")
+    ap.add_argument("--group", type=int, default=None, help="cfg.pairFrames = N: N frames per warp+fuse launch (2..4; default: as many as "
+                    "one launch takes, 4 at x2 Bayer, else 2)")
     ap.add_argument("--async-fuse", action="store_true", help="(default since round 2: cfg.asyncFuse = 1) accepted for compatibility")
     ap.add_argument("--no-async-fuse", action="store_true",
                     help="cfg.asyncFuse = 0: warp+fuse launches on the caller's stream instead of the burst's own (A/B: -5 %)")
@@ -211,6 +214,8 @@ def main():
     cfg.fused = 0 if args.unfused else 1
     if args.no_pair:
         cfg.pairFrames = 0
+    if args.group is not None:
+        cfg.pairFrames = args.group
     if args.no_async_fuse:
         cfg.asyncFuse = 0
     if world == 1:
@@ -436,7 +441,7 @@ def main():
             pl = _capi.StripePlan()
             LIB.dist_stripe_plan(ctypes.byref(cfg), world, 0, 64, ctypes.byref(pl))
             row_frac = (pl.rowEnd - pl.rowBegin) / float(H * s)
-        n_launch_burst, bytes_burst = burst_fuse_bytes(W, H, s, mono, fused_per_rank, bool(cfg.pairFrames))
+        n_launch_burst, bytes_burst = burst_fuse_bytes(W, H, s, mono, fused_per_rank, int(LIB.raw["mfsr_burst_group_size"](ctypes.byref(cfg))))
         bytes_launch = bytes_burst / n_launch_burst * row_frac
         frames_per_launch = fused_frames.value / max(launches.value, 1)
         bytes_ref_launch = fuse_bytes_reference_structure(W, H, s, mono) * frames_per_launch * row_frac

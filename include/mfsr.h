@@ -42,6 +42,7 @@ extern "C" {
 #endif
 
 #define MFSR_VERSION 100
+#define MFSR_MAX_FUSE_GROUP 4 /* frames one warp+fuse call takes (mfsr_accumulateSuperResFullN, cfg.pairFrames) */
 
 typedef void* mfsr_stream_t; /* hipStream_t */
 
@@ -119,7 +120,9 @@ int mfsr_accumulateSuperResFull2(const uint16_t* dataIn0, const uint16_t* dataIn
                                  mfsr_tex2d shifts1, mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY,
                                  int scale, int strideOut, int strideMask, mfsr_stream_t stream);
 
-/* nFrames (1 or 2) frames in one call (dataIn / certaintyMask / shifts: host arrays of nFrames entries).
+/* nFrames (1 .. MFSR_MAX_FUSE_GROUP) frames in one call (dataIn / certaintyMask / shifts: host arrays of nFrames entries);
+ * the frames add in call order.  At scale 2 with the fields at a quarter of the HR size (the Bayer pipeline) the whole group
+ * is ONE pass over the accumulators; other geometries take it two frames at a time.
  * accumulatorsUndefined != 0: imgOut / totalWeights are OVERWRITTEN as if they had been zeroed before
  * the call -- the first launch of a burst needs neither the memset nor the read of the two planes. */
 int mfsr_accumulateSuperResFullN(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
@@ -416,7 +419,9 @@ typedef struct {
     float weightThreshold;
     int32_t applyGamma;
     int32_t fused;           /* 1: fused MI355X kernels; 0: one launch per reference kernel */
-    int32_t pairFrames;      /* 1: add_frame fuses frames two at a time (see mfsr_burst_add_frame) */
+    int32_t pairFrames;      /* frames per warp+fuse launch of add_frame (see mfsr_burst_add_frame): 0 = one, like the
+                                reference; 1 (default) = as many as one launch takes (MFSR_MAX_FUSE_GROUP at scale 2, else 2);
+                                2 .. MFSR_MAX_FUSE_GROUP = that many */
     int32_t asyncFuse;       /* 1 (default): the warp+fuse launches run on a stream owned by the burst, concurrently with the
                                 alignment of the following frames on the caller's stream (see mfsr_burst_add_frame) */
     int32_t preAlign;        /* 1: estimate a global base shift + rotation per moved frame (mfsr_preAlign) and feed it to
@@ -444,11 +449,12 @@ int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, mfsr_stream_
 /* Align + robustness + accumulate ONE frame into the caller's accumulators
  * (float3 HR, pitch 12*scale*width; zeroed by the caller before the first
  * call).  isReference != 0: identity flow, certainty 1.
- * With cfg.pairFrames the warp+fuse of a frame is deferred until the next frame is aligned and
- * both are fused in one pass over the accumulators (half the accumulator traffic): after an
- * odd number of calls one frame is still waiting -- its raw buffer must stay untouched and the
- * accumulators do not contain it -- until the next add_frame, mfsr_burst_flush, finish or
- * finish_rows has been issued on the stream.
+ * With cfg.pairFrames the warp+fuse of a frame is deferred until its group (2 .. MFSR_MAX_FUSE_GROUP frames,
+ * mfsr_burst_group_size) is aligned and the whole group is fused in one pass over the accumulators (a fraction of the
+ * accumulator traffic, and everything that depends on the reference only -- kernel parameters, tap weights -- once
+ * per pixel): between groups up to group - 1 frames are still waiting -- their raw buffers must stay untouched and
+ * the accumulators do not contain them -- until the next add_frame, mfsr_burst_flush, finish or finish_rows has been
+ * issued on the stream.
  * With cfg.asyncFuse the warp+fuse launches go to a high-priority stream the burst owns (ordered by
  * events after the alignment on the caller's stream), so the fuse of frames k, k+1 overlaps the
  * alignment of k+2, k+3.  The caller's stream sees the accumulators complete only after
@@ -495,7 +501,9 @@ int mfsr_burst_field_dims(const mfsr_burst* b, int* flowW, int* flowH, int* mask
 /* stages A1, (I), B, D, F of mfsr_burst_add_frame without G; results copied to flowOut / maskOut (byte pitches) */
 int mfsr_burst_align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float2* flowOut, int flowPitch,
                            mfsr_float4* maskOut, int maskPitch, mfsr_stream_t stream);
-/* stage G for 1 or 2 aligned frames on HR rows [rowBegin, rowEnd) (see mfsr_accumulateSuperResFullRows), with the kernel
+/* frames per warp+fuse launch cfg.pairFrames stands for with this configuration (1 .. MFSR_MAX_FUSE_GROUP) */
+int mfsr_burst_group_size(const mfsr_config* cfg);
+/* stage G for 1 .. MFSR_MAX_FUSE_GROUP aligned frames on HR rows [rowBegin, rowEnd) (see mfsr_accumulateSuperResFullRows), with the kernel
  * parameters of the burst's reference */
 int mfsr_burst_fuse_rows(mfsr_burst* b, int nFrames, const uint16_t* const* raws, const mfsr_float2* const* flows, int flowPitch,
                          const mfsr_float4* const* masks, int maskPitch, mfsr_float3* imgOut, mfsr_float3* totalWeights,

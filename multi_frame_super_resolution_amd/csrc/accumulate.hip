@@ -233,7 +233,7 @@ extern "C" int mfsr_accumulateSuperResFullRows(int nFrames, const uint16_t* cons
                                                int strideMask, int accumulatorsUndefined, int rowBegin, int rowEnd,
                                                mfsr_stream_t stream)
 {
-    MFSR_REQUIRE(nFrames >= 1 && nFrames <= 2 && dataIn && certaintyMask && shifts);
+    MFSR_REQUIRE(nFrames >= 1 && nFrames <= MFSR_MAX_FUSE_GROUP && dataIn && certaintyMask && shifts);
     MFSR_REQUIRE(scale >= 1 && scale <= 8);
     const int hrH = scale * dimY;
     MFSR_REQUIRE(rowBegin >= 0 && rowBegin < rowEnd && rowEnd <= hrH && (rowBegin % 16) == 0 && ((rowEnd % 16) == 0 || rowEnd == hrH));
@@ -249,6 +249,16 @@ extern "C" int mfsr_accumulateSuperResFullRows(int nFrames, const uint16_t* cons
                                                          rowEnd, stream);
         if (r == 1) return mfsr_launch_status("accumulateSuperResFullN(strip)");
         if (r < 0) return MFSR_E_INVALID;
+    }
+    if (nFrames > 2) {
+        // no kernel of this geometry takes the whole group: two frames, then the rest
+        const int rc = mfsr_accumulateSuperResFullRows(2, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, whiteLevel,
+                                                       blackLevel, dimX, dimY, scale, strideOut, strideMask, accumulatorsUndefined,
+                                                       rowBegin, rowEnd, stream);
+        if (rc) return rc;
+        return mfsr_accumulateSuperResFullRows(nFrames - 2, dataIn + 2, imgOut, totalWeights, certaintyMask + 2, kernelParam,
+                                               shifts + 2, whiteLevel, blackLevel, dimX, dimY, scale, strideOut, strideMask, 0,
+                                               rowBegin, rowEnd, stream);
     }
     if (g_accumulate_fast == 2 && scale == 4) {
         const int r = mfsr_try_launch_accumulate4x_tile(nFrames, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts,

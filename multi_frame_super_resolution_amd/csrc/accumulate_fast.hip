@@ -377,6 +377,47 @@ struct TileFrames {
     TileFrame f[NF];
 };
 
+// the margin pixels of NF frames in one launch: the accumulators of a pixel are read and written once, its frames add in
+// call order (the same sums, in the same order, as NF launches of k_accumulateMargin)
+template <int NF>
+__global__ void __launch_bounds__(256)
+    k_accumulateMarginN(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
+                        Levels3 glv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int scale, int rowBegin,
+                        int rowEnd)
+{
+    const int hrW = scale * dimX, hrH = scale * dimY, M = STRIP_MARGIN;
+    const int rowLen = hrW - 2;
+    const int nTop = (M - 1) * rowLen, nBot = (M - 1) * rowLen;
+    const int sideLen = 2 * (M - 1);
+    const int nSide = (hrH - 2 * M) * sideLen;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int x, y;
+    if (idx < nTop) {
+        y = 1 + idx / rowLen;
+        x = 1 + idx % rowLen;
+    } else if (idx < nTop + nBot) {
+        const int r = idx - nTop;
+        y = hrH - M + r / rowLen;
+        x = 1 + r % rowLen;
+    } else if (idx < nTop + nBot + nSide) {
+        const int r = idx - nTop - nBot;
+        y = M + r / sideLen;
+        const int c = r % sideLen;
+        x = c < M - 1 ? 1 + c : hrW - M + (c - (M - 1));
+    } else {
+        return;
+    }
+    if (y < rowBegin || y >= rowEnd) return;
+    pix3 pixel = row_ptr(imgOut, strideOut, y)[x];
+    pix3 totalWeight = row_ptr(totalWeights, strideOut, y)[x];
+#pragma unroll
+    for (int n = 0; n < NF; n++)
+        accumulate_pixel_core<GEOM_FULL, true>(x, y, fr.f[n].raw, fr.f[n].mask, kernelParam, fr.f[n].shifts, glv, dimX, dimY, scale,
+                                               strideMask, cfaPacked, pixel, totalWeight);
+    row_ptr(imgOut, strideOut, y)[x] = pixel;
+    row_ptr(totalWeights, strideOut, y)[x] = totalWeight;
+}
+
 // one frame of one strip on the register-resident accumulators (k_accumulate2xStrip)
 template <int CFA, int FR>
 __device__ __forceinline__ void strip_frame(int tx, int Y, int X0, const uint16_t* __restrict__ raw,
@@ -558,7 +599,7 @@ __global__ void __launch_bounds__(256)
 #define TILE_WAVES 4
 #endif
 #ifndef TILE_WAVES2
-#define TILE_WAVES2 3
+#define TILE_WAVES2 4
 #endif
 #define TILE_WAVES_NF(NF) ((NF) == 1 ? TILE_WAVES : TILE_WAVES2)
 // two frames per launch: pixel-major order with the tap weights shared by both frames (0: frame-major, weights per frame)
@@ -592,7 +633,10 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     __shared__ __attribute__((aligned(16))) float sColA[256];  // x fraction per HR column of the tile, -1 = not on the predicted texel
     __shared__ float sRowB[4];                                 // y fraction per HR row of the tile, -1 likewise
     // accumulator staging: per wave and plane-set the wave's 3 KiB row segment, in memory order
-    __shared__ __attribute__((aligned(16))) float4 sAcc[4][2][192];
+    // (three and four frames per launch: one plane-set at a time through the same 3 KiB, or four workgroups per CU would
+    // not fit the 160 KiB -- the pixel sums wait in registers, the second plane-set's load is the only exposed latency)
+    constexpr int PL = NF <= 2 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float4 sAcc[4][PL][192];
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int tx = bIdX * 64 + lx;
     const int Y = bIdY * 4 + ly;
@@ -648,24 +692,24 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     const size_t segByte = (size_t)bIdX * 3072;
     char* gP = (char*)imgOut + (size_t)Y * strideOut + segByte;
     char* gW = (char*)totalWeights + (size_t)Y * strideOut + segByte;
-    if (rowLive && fresh) {
-        // first launch of a burst: the accumulators are defined to be zero and are not read at all
+    // plane-set g (this wave's row segment) -> LDS plane pl: zeroes on the first launch of a burst (the accumulators are
+    // defined to be zero and are not read at all), else the asynchronous copy
+    auto stage_plane = [&](char* g, int pl) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            sAcc[ly][0][j * 64 + lx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            sAcc[ly][1][j * 64 + lx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-    } else if (rowLive) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const size_t off = (size_t)(j * 64 + lx) * 16;
-            if (segByte + off + 16 <= rowBytes) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gP + off),
-                                                 (__attribute__((address_space(3))) void*)&sAcc[ly][0][j * 64], 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW + off),
-                                                 (__attribute__((address_space(3))) void*)&sAcc[ly][1][j * 64], 16, 0, 0);
+            if (fresh) {
+                sAcc[ly][pl][j * 64 + lx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            } else {
+                const size_t off = (size_t)(j * 64 + lx) * 16;
+                if (segByte + off + 16 <= rowBytes)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + off),
+                                                     (__attribute__((address_space(3))) void*)&sAcc[ly][pl][j * 64], 16, 0, 0);
             }
         }
+    };
+    if (rowLive) {
+        stage_plane(gP, 0);
+        if (PL == 2) stage_plane(gW, 1);
     }
     __syncthreads();
     if (!rowLive) return;
@@ -706,6 +750,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     for (int i = 0; i < 12; i++) accP[i] = accW[i] = 0.0f;
     const uint32_t xmax = (uint32_t)(2 * dimX - 5), ymax = (uint32_t)(2 * dimY - 5);
     uint32_t safeBits = 0;  // bit n: frame n took the fast path
+    static_assert(NF <= 2 || TILE_PIXEL_MAJOR, "three and four frames per launch exist in pixel-major order only");
 #if TILE_PIXEL_MAJOR
     if constexpr (NF > 1) {
         // Two frames, pixel-major: the 13 tap weights of a pixel (12 v_exp_f32 and their exponents: a fifth of the
@@ -837,52 +882,80 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
         }
     }
     }
-    float* myP = (float*)&sAcc[ly][0][0] + lx * 12;  // this lane's 4 pixels x 3 channels inside the staged segment
-    float* myW = (float*)&sAcc[ly][1][0] + lx * 12;
-    // staged accumulators must have landed before anyone reads them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (safeBits) {
+    // staged plane pl += this lane's 4 pixels x 3 channels
+    auto add_plane = [&](int pl, const float* acc) {
+        float4* my = (float4*)((float*)&sAcc[ly][pl][0] + lx * 12);
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            float4 a = ((float4*)myP)[j], c = ((float4*)myW)[j];
-            a.x += accP[4 * j + 0]; a.y += accP[4 * j + 1]; a.z += accP[4 * j + 2]; a.w += accP[4 * j + 3];
-            c.x += accW[4 * j + 0]; c.y += accW[4 * j + 1]; c.z += accW[4 * j + 2]; c.w += accW[4 * j + 3];
-            ((float4*)myP)[j] = a;
-            ((float4*)myW)[j] = c;
+            float4 a = my[j];
+            a.x += acc[4 * j + 0]; a.y += acc[4 * j + 1]; a.z += acc[4 * j + 2]; a.w += acc[4 * j + 3];
+            my[j] = a;
         }
-    }
+    };
+    // border / wild-flow / non-PSD strips of a frame: the straight per-pixel arithmetic on the staged values (after the
+    // sums have left the registers: it needs most of them).  With one staged plane-set at a time it runs once per set
+    // and keeps that set's result only -- these strips are a few per frame.
+    auto slow_frames = [&](auto doP, auto doW, int plP, int plW) {
+        constexpr bool DO_P = decltype(doP)::value, DO_W = decltype(doW)::value;
+        float* myP = (float*)&sAcc[ly][plP][0] + lx * 12;
+        float* myW = (float*)&sAcc[ly][plW][0] + lx * 12;
 #pragma unroll 1
-    for (int n = 0; n < NF; n++) {
-        const TileFrame& F = (NF > 1 && n) ? fr.f[NF - 1] : fr.f[0];
-        if (!((safeBits >> n) & 1u) && stripLive) {
-            // border / wild-flow / non-PSD strips: the straight per-pixel arithmetic on the staged values
+        for (int n = 0; n < NF; n++) {
+            if (!((safeBits >> n) & 1u) && stripLive) {
+                // the frame's arguments picked with scalar selects: the argument struct stays in SGPRs
+                TileFrame F = fr.f[0];
+#pragma unroll
+                for (int m = 1; m < NF; m++)
+                    if (n == m) F = fr.f[m];
 #pragma unroll 1
-            for (int k = 0; k < 4; k++) {
-                const int X = X0 + k;
-                if (X >= 1 && X < hrW - 1) {
-                    pix3 px = {myP[3 * k], myP[3 * k + 1], myP[3 * k + 2]};
-                    pix3 tw = {myW[3 * k], myW[3 * k + 1], myW[3 * k + 2]};
-                    accumulate_pixel_core<GEOM_FULL, true>(X, Y, F.raw, F.mask, kernelParam, F.shifts, glv, dimX, dimY, 2,
-                                                           strideMask, cfaPacked, px, tw);
-                    myP[3 * k] = px.x; myP[3 * k + 1] = px.y; myP[3 * k + 2] = px.z;
-                    myW[3 * k] = tw.x; myW[3 * k + 1] = tw.y; myW[3 * k + 2] = tw.z;
+                for (int k = 0; k < 4; k++) {
+                    const int X = X0 + k;
+                    if (X >= 1 && X < hrW - 1) {
+                        pix3 px = {0.0f, 0.0f, 0.0f}, tw = {0.0f, 0.0f, 0.0f};
+                        if (DO_P) px = {myP[3 * k], myP[3 * k + 1], myP[3 * k + 2]};
+                        if (DO_W) tw = {myW[3 * k], myW[3 * k + 1], myW[3 * k + 2]};
+                        accumulate_pixel_core<GEOM_FULL, true>(X, Y, F.raw, F.mask, kernelParam, F.shifts, glv, dimX, dimY, 2,
+                                                               strideMask, cfaPacked, px, tw);
+                        if (DO_P) { myP[3 * k] = px.x; myP[3 * k + 1] = px.y; myP[3 * k + 2] = px.z; }
+                        if (DO_W) { myW[3 * k] = tw.x; myW[3 * k + 1] = tw.y; myW[3 * k + 2] = tw.z; }
+                    }
                 }
             }
         }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // write the segment back in memory order: contiguous 1 KiB per store instruction
+    };
+    // staged plane pl back to g in memory order: contiguous 1 KiB per store instruction
+    auto store_plane = [&](int pl, char* g) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const size_t off = (size_t)(j * 64 + lx) * 16;
-        // the 16-pixel side margins of the row belong to k_accumulateMargin, which may run concurrently on the margin
-        // stream: their (unchanged) chunks are not written back.  A fresh launch defines them (zero) instead.
-        const size_t g = segByte + off;
-        const bool sideMargin = g < (size_t)STRIP_MARGIN * 12 || g + 16 > rowBytes - (size_t)STRIP_MARGIN * 12;
-        if (g + 16 <= rowBytes && (fresh || !sideMargin)) {
-            *(float4*)(gP + off) = sAcc[ly][0][j * 64 + lx];
-            *(float4*)(gW + off) = sAcc[ly][1][j * 64 + lx];
+        for (int j = 0; j < 3; j++) {
+            const size_t off = (size_t)(j * 64 + lx) * 16;
+            // the 16-pixel side margins of the row belong to k_accumulateMargin, which may run concurrently on the margin
+            // stream: their (unchanged) chunks are not written back.  A fresh launch defines them (zero) instead.
+            const size_t gb = segByte + off;
+            const bool sideMargin = gb < (size_t)STRIP_MARGIN * 12 || gb + 16 > rowBytes - (size_t)STRIP_MARGIN * 12;
+            if (gb + 16 <= rowBytes && (fresh || !sideMargin)) *(float4*)(g + off) = sAcc[ly][pl][j * 64 + lx];
         }
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+    // staged accumulators must have landed before anyone reads them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (PL == 2) {
+        add_plane(0, accP);
+        add_plane(1, accW);
+        if (safeBits != (1u << NF) - 1u) slow_frames(Yes{}, Yes{}, 0, 1);
+        store_plane(0, gP);
+        store_plane(1, gW);
+    } else {
+        add_plane(0, accP);
+        if (safeBits != (1u << NF) - 1u) slow_frames(Yes{}, No{}, 0, 0);
+        store_plane(0, gP);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // plane 0 has been read out before the copy overwrites it
+        stage_plane(gW, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        add_plane(0, accW);
+        if (safeBits != (1u << NF) - 1u) slow_frames(No{}, Yes{}, 0, 0);
+        store_plane(0, gW);
     }
 }
 
@@ -1317,11 +1390,11 @@ void read_env_once()
 
 }  // namespace
 
-// Returns 1 if the fast kernels were launched for all `nFrames` (1 or 2) frames, 0 if the
-// configuration is not one they handle (caller falls back to the straight kernel), -1 if a memset of
-// the fresh-accumulator mode failed.
-// With two frames the LDS tile kernel fuses both in one pass over the accumulators; the other
-// geometries run frame after frame.
+// Returns 1 if the fast kernels were launched for all `nFrames` (1 to 4) frames, 0 if the
+// configuration is not one they handle (caller falls back to the straight kernel, or splits a group of
+// three or four), -1 if a memset of the fresh-accumulator mode failed.
+// With two to four frames the LDS tile kernel fuses all of them in one pass over the accumulators; the other
+// geometries take at most two, frame after frame.
 int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
                                        mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
                                        mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
@@ -1329,7 +1402,7 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
                                        int fresh, int rowBegin, int rowEnd, mfsr_stream_t stream)
 {
     read_env_once();
-    if (nFrames < 1 || nFrames > 2) return 0;
+    if (nFrames < 1 || nFrames > 4) return 0;
     int cfa[4];
     mfsr_get_cfa_pattern(cfa);
     for (int i = 0; i < 4; i++)
@@ -1355,8 +1428,10 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
     pix3* pI = (pix3*)imgOut;
     pix3* pT = (pix3*)totalWeights;
     const int cp = mfsr_cfa_packed();
-    const bool pair = nFrames == 2 && tile_kernel_ok(kernelParam, shifts[0], dimX, dimY) &&
-                      tile_kernel_ok(kernelParam, shifts[1], dimX, dimY);
+    // two to four frames in one pass over the accumulators: the LDS tile kernel's geometry only
+    bool pair = nFrames >= 2;
+    for (int n = 0; n < nFrames; n++) pair = pair && tile_kernel_ok(kernelParam, shifts[n], dimX, dimY);
+    if (nFrames > 2 && !pair) return 0;  // the caller splits the group
     // fresh accumulators ("as if zeroed", never read): the tile kernels write every row outside the top
     // and bottom margin bands themselves, the bands are zeroed here; the other kernels get a full memset
     const bool tileFirst = pair || (nFrames == 1 && tile_kernel_ok(kernelParam, shifts[0], dimX, dimY));
@@ -1386,19 +1461,33 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
             (void)hipStreamWaitEvent(st, msx->join, 0);
         }
     };
+    // NF frames: the tile kernel, then their margin pixels in one launch
+    auto launch_group = [&](auto cfaTag, auto nfTag) {
+        constexpr int CFA = decltype(cfaTag)::value, NF = decltype(nfTag)::value;
+        TileFrames<NF> fr;
+        for (int n = 0; n < NF; n++) {
+            fr.f[n].raw = dataIn[n];
+            fr.f[n].mask = (const float4*)certaintyMask[n];
+            fr.f[n].shifts = shifts[n];
+        }
+        launch_tile<CFA, NF>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY, strideOut, strideMask, cp, tileFresh,
+                             rowBlock0);
+        const int M = STRIP_MARGIN;
+        const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
+        hipLaunchKernelGGL(k_accumulateMarginN<NF>, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, mst, fr, pI, pT, kernelParam, glv, dimX,
+                           dimY, strideOut, strideMask, cp, 2, rowBegin, rowEnd);
+        if (msx) {
+            (void)hipEventRecord(msx->join, msx->stream);
+            (void)hipStreamWaitEvent(st, msx->join, 0);
+        }
+    };
 #define STRIP_CASE(a, b, c, d)                                                                                         \
     case pack_cfa(a, b, c, d):                                                                                         \
         if (pair) {                                                                                                    \
-            TileFrames<2> fr;                                                                                          \
-            for (int n = 0; n < 2; n++) {                                                                              \
-                fr.f[n].raw = dataIn[n];                                                                               \
-                fr.f[n].mask = (const float4*)certaintyMask[n];                                                        \
-                fr.f[n].shifts = shifts[n];                                                                            \
-            }                                                                                                          \
-            launch_tile<pack_cfa(a, b, c, d), 2>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY, strideOut, \
-                                                 strideMask, cp, tileFresh, rowBlock0);                                           \
-            launch_margin(0);                                                                                          \
-            launch_margin(1);                                                                                          \
+            using CfaTag = std::integral_constant<int, pack_cfa(a, b, c, d)>;                                          \
+            if (nFrames == 2) launch_group(CfaTag{}, std::integral_constant<int, 2>{});                                \
+            if (nFrames == 3) launch_group(CfaTag{}, std::integral_constant<int, 3>{});                                \
+            if (nFrames == 4) launch_group(CfaTag{}, std::integral_constant<int, 4>{});                                \
         } else if (nFrames == 2) {                                                                                     \
             TileFrames<2> fr;                                                                                          \
             for (int n = 0; n < 2; n++) {                                                                              \

@@ -311,19 +311,24 @@ static int process_stripes(mfsr_dist* d, const uint16_t* const* frames, uint16_t
     D_HIP(hipEventRecord(d->evExchanged, B));
     D_HIP(hipStreamWaitEvent(st, d->evExchanged, 0));
 
-    // every frame, in frame order, two per pass over the accumulators, onto this rank's HR rows only
+    // every frame, in frame order, a group per pass over the accumulators, onto this rank's HR rows only
     if (mine.rowEnd > mine.rowBegin) {
         // (a halo that spans the whole frame needs no check: every raw row is present)
         for (int k = 0; k < N && mine.rawRows < c.height; k++)
             D_TRY(mfsr_checkFlowBound((const mfsr_float2*)((const char*)d->flow(k) + (size_t)mine.flowRow0 * L.flowPitch), L.flowPitch, L.tw,
                                       mine.flowRows, mine.maxFlowY, flag, (mfsr_stream_t)st));
-        const int per = c.pairFrames ? 2 : 1;
+        const int per = mfsr_burst_group_size(&c);  // the grouping of the single-GPU burst: same sums in the same order
         for (int k = 0; k < N; k += per) {
             const int n = (k + per <= N) ? per : N - k;
-            const uint16_t* r2[2] = {raws[k], n == 2 ? raws[k + 1] : nullptr};
-            const mfsr_float2* f2[2] = {d->flow(k), n == 2 ? d->flow(k + 1) : nullptr};
-            const mfsr_float4* m2[2] = {d->mask(k), n == 2 ? d->mask(k + 1) : nullptr};
-            D_TRY(mfsr_burst_fuse_rows(d->burst, n, r2, f2, L.flowPitch, m2, L.maskPitch, d->imgOut, d->totalWeights, k == 0 ? 1 : 0,
+            const uint16_t* rg[MFSR_MAX_FUSE_GROUP];
+            const mfsr_float2* fg[MFSR_MAX_FUSE_GROUP];
+            const mfsr_float4* mg[MFSR_MAX_FUSE_GROUP];
+            for (int j = 0; j < n; j++) {
+                rg[j] = raws[k + j];
+                fg[j] = d->flow(k + j);
+                mg[j] = d->mask(k + j);
+            }
+            D_TRY(mfsr_burst_fuse_rows(d->burst, n, rg, fg, L.flowPitch, mg, L.maskPitch, d->imgOut, d->totalWeights, k == 0 ? 1 : 0,
                                        mine.rowBegin, mine.rowEnd, (mfsr_stream_t)st));
         }
         uint16_t* dst = me == 0 ? out16 : d->out16;

@@ -37,7 +37,7 @@ constexpr int kMaxTimedLaunches = 4096;
 // Per-frame products (flow, certainty mask) live in a ring of kRing slots: a frame's slot stays
 // untouched until the warp+fuse that consumes it has run, which with cfg.asyncFuse happens on the
 // burst's own stream while the caller's stream already aligns the next frames.
-constexpr int kRing = 4;
+constexpr int kRing = 2 * MFSR_MAX_FUSE_GROUP;  // a group waiting to be fused + the group the fuse stream is reading
 constexpr int kMaxUploadRing = 16;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -135,6 +135,7 @@ int validate(const mfsr_config* c)
     MFSR_REQUIRE(c->maxVal > 0);
     if (c->preAlign) MFSR_REQUIRE(c->preAlignMaxAngle >= 0.0f && c->preAlignMaxAngle <= 45.0f);
     MFSR_REQUIRE(c->uploadRing == 0 || (c->uploadRing >= 3 && c->uploadRing <= kMaxUploadRing));
+    MFSR_REQUIRE(c->pairFrames >= 0 && c->pairFrames <= MFSR_MAX_FUSE_GROUP);
     return MFSR_OK;
 }
 
@@ -237,16 +238,17 @@ struct mfsr_burst {
     Img* flowCur;  // flow of the last add_frame (raw-pixel units)
     Img* maskCur;  // certainty mask of the last add_frame
     bool haveRef;
-    // frame pairing (cfg.pairFrames): an aligned frame waits here until the next one is aligned, then
-    // both are fused in one pass over the accumulators; flush/finish fuses a frame left alone
+    // frame grouping (cfg.pairFrames): aligned frames wait here until their group is complete, then the
+    // group is fused in one pass over the accumulators; flush/finish fuses what is left of a group
     struct Pending {
-        bool has;
-        int slot;
-        const uint16_t* raw;
-        Img* flow;
-        Img* mask;
+        int n;  // frames waiting (0 .. group - 1)
+        int slot[MFSR_MAX_FUSE_GROUP];
+        const uint16_t* raw[MFSR_MAX_FUSE_GROUP];
+        Img* flow[MFSR_MAX_FUSE_GROUP];
+        Img* mask[MFSR_MAX_FUSE_GROUP];
         mfsr_float3 *imgOut, *totalWeights;
     } pend;
+    int group;  // frames per warp+fuse launch (mfsr_burst_group_size)
     int nFramesTimed;
     // mfsr_burst_begin: these accumulators are to be overwritten by the first fuse instead of zeroed
     struct Fresh {
@@ -384,7 +386,8 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     b->ntensorTaps = mfsr_gaussin_filter_1D(cfg->sigmaTensor, b->tensorTaps);
     b->flowCur = &b->L.flowBuf[0];
     b->maskCur = &b->L.maskBuf[0];
-    b->pend.has = false;
+    b->pend.n = 0;
+    b->group = mfsr_burst_group_size(&b->cfg);
     b->fresh.has = false;
     b->nFramesTimed = 0;
     b->timing = false;
@@ -659,19 +662,22 @@ static int upload_slot_of(const mfsr_burst* b, const uint16_t* raw)
     return -1;
 }
 
-// G: one or two aligned frames onto the caller's accumulators (timed with HIP events on request)
-static int accumulate_frames(mfsr_burst* b, int n, int slot0, int slot1, const uint16_t* raw0, const uint16_t* raw1,
-                             Img* flow0, Img* flow1, Img* mask0, Img* mask1, mfsr_float3* imgOut,
-                             mfsr_float3* totalWeights, mfsr_stream_t callerStream)
+// G: the waiting group (b->pend, 1 .. MFSR_MAX_FUSE_GROUP aligned frames) onto its accumulators (timed with HIP events on request)
+static int accumulate_pending(mfsr_burst* b, mfsr_stream_t callerStream)
 {
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
+    const mfsr_burst::Pending p = b->pend;
+    b->pend.n = 0;
+    const int n = p.n;
+    if (n == 0) return MFSR_OK;
+    mfsr_float3* imgOut = p.imgOut;
+    mfsr_float3* totalWeights = p.totalWeights;
     // with asyncFuse the launch goes to the burst's own stream, ordered after the alignment of its frames
     mfsr_stream_t stream = callerStream;
     if (b->fuseStream) {
         stream = (mfsr_stream_t)b->fuseStream;
-        MFSR_HIP_TRY(hipStreamWaitEvent(b->fuseStream, b->evAligned[slot0], 0));
-        if (n == 2) MFSR_HIP_TRY(hipStreamWaitEvent(b->fuseStream, b->evAligned[slot1], 0));
+        for (int i = 0; i < n; i++) MFSR_HIP_TRY(hipStreamWaitEvent(b->fuseStream, b->evAligned[p.slot[i]], 0));
     }
     const mfsr_float3 white = {c.white[0], c.white[1], c.white[2]};
     const mfsr_float3 black = {c.black[0], c.black[1], c.black[2]};
@@ -685,9 +691,12 @@ static int accumulate_frames(mfsr_burst* b, int n, int slot0, int slot1, const u
         MFSR_HIP_TRY(hipEventRecord(b->evStart[i], mfsr_s(stream)));
     }
     {
-        const uint16_t* raws[2] = {raw0, raw1};
-        const mfsr_float4* masks[2] = {(const mfsr_float4*)mask0->ptr, n == 2 ? (const mfsr_float4*)mask1->ptr : nullptr};
-        const mfsr_tex2d flows[2] = {as_tex(*flow0), n == 2 ? as_tex(*flow1) : as_tex(*flow0)};
+        const mfsr_float4* masks[MFSR_MAX_FUSE_GROUP];
+        mfsr_tex2d flows[MFSR_MAX_FUSE_GROUP];
+        for (int i = 0; i < n; i++) {
+            masks[i] = (const mfsr_float4*)p.mask[i]->ptr;
+            flows[i] = as_tex(*p.flow[i]);
+        }
         // the first fuse after mfsr_burst_begin overwrites the accumulators (they are not zeroed or read)
         const int freshNow = b->fresh.has && b->fresh.imgOut == imgOut && b->fresh.totalWeights == totalWeights;
         if (b->fresh.has && !freshNow) {
@@ -697,8 +706,8 @@ static int accumulate_frames(mfsr_burst* b, int n, int slot0, int slot1, const u
             MFSR_HIP_TRY(hipMemsetAsync(b->fresh.totalWeights, 0, bytes, mfsr_s(stream)));
         }
         b->fresh.has = false;
-        TRY(mfsr_accumulateSuperResFullN(n, raws, imgOut, totalWeights, masks, as_tex(L.kparam4), flows, white, black, L.W, L.H,
-                                         c.scale, strideOut, mask0->pitch, freshNow, stream));
+        TRY(mfsr_accumulateSuperResFullN(n, p.raw, imgOut, totalWeights, masks, as_tex(L.kparam4), flows, white, black, L.W, L.H,
+                                         c.scale, strideOut, p.mask[0]->pitch, freshNow, stream));
     }
     if (timed) {
         MFSR_HIP_TRY(hipEventRecord(b->evStop[b->nEvents], mfsr_s(stream)));
@@ -707,9 +716,8 @@ static int accumulate_frames(mfsr_burst* b, int n, int slot0, int slot1, const u
     }
     if (b->copyStream) {
         // upload slots whose raw frame this launch was the last to read may be overwritten once it has run
-        const uint16_t* raws2[2] = {raw0, n == 2 ? raw1 : nullptr};
-        for (int j = 0; j < 2; j++) {
-            const int us = upload_slot_of(b, raws2[j]);
+        for (int j = 0; j < n; j++) {
+            const int us = upload_slot_of(b, p.raw[j]);
             if (us >= 0) {
                 MFSR_HIP_TRY(hipEventRecord(b->evFree[us], mfsr_s(stream)));
                 b->freeRecorded[us] = true;
@@ -717,11 +725,9 @@ static int accumulate_frames(mfsr_burst* b, int n, int slot0, int slot1, const u
         }
     }
     if (b->fuseStream) {
-        MFSR_HIP_TRY(hipEventRecord(b->evFused[slot0], b->fuseStream));
-        b->fusedOutstanding[slot0] = true;
-        if (n == 2) {
-            MFSR_HIP_TRY(hipEventRecord(b->evFused[slot1], b->fuseStream));
-            b->fusedOutstanding[slot1] = true;
+        for (int i = 0; i < n; i++) {
+            MFSR_HIP_TRY(hipEventRecord(b->evFused[p.slot[i]], b->fuseStream));
+            b->fusedOutstanding[p.slot[i]] = true;
         }
     }
     return MFSR_OK;
@@ -739,22 +745,17 @@ static int join_fuse(mfsr_burst* b, mfsr_stream_t stream)
     return MFSR_OK;
 }
 
-// fuse a frame still waiting for its partner, then join: afterwards the caller's stream sees every frame
+// fuse the frames still waiting for the rest of their group, then join: afterwards the caller's stream sees every frame
 static int flush_pending(mfsr_burst* b, mfsr_stream_t stream, bool materializeFresh)
 {
-    if (materializeFresh && b->fresh.has && !b->pend.has) {
+    if (materializeFresh && b->fresh.has && b->pend.n == 0) {
         // mfsr_burst_begin with no frame fused since: the accumulators must read as zero
         const size_t bytes = (size_t)12 * b->L.hrW * b->L.hrH;
         MFSR_HIP_TRY(hipMemsetAsync(b->fresh.imgOut, 0, bytes, mfsr_s(stream)));
         MFSR_HIP_TRY(hipMemsetAsync(b->fresh.totalWeights, 0, bytes, mfsr_s(stream)));
         b->fresh.has = false;
     }
-    if (b->pend.has) {
-        mfsr_burst::Pending p = b->pend;
-        b->pend.has = false;
-        TRY(accumulate_frames(b, 1, p.slot, -1, p.raw, nullptr, p.flow, nullptr, p.mask, nullptr, p.imgOut, p.totalWeights,
-                              stream));
-    }
+    TRY(accumulate_pending(b, stream));
     return join_fuse(b, stream);
 }
 
@@ -865,23 +866,24 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
     b->maskCur = mask;
     if (b->fuseStream) MFSR_HIP_TRY(hipEventRecord(b->evAligned[slot], mfsr_s(stream)));
     // G: accumulate onto the HR grid -- alone, or together with the frame that was waiting for a partner
-    if (b->pend.has && (b->pend.imgOut != imgOut || b->pend.totalWeights != totalWeights)) TRY(flush_pending(b, stream));
-    if (b->pend.has) {
-        mfsr_burst::Pending p = b->pend;
-        b->pend.has = false;
-        return accumulate_frames(b, 2, p.slot, slot, p.raw, raw, p.flow, flow, p.mask, mask, imgOut, totalWeights, stream);
-    }
-    if (c.pairFrames) {
-        b->pend.has = true;
-        b->pend.slot = slot;
-        b->pend.raw = raw;
-        b->pend.flow = flow;
-        b->pend.mask = mask;
-        b->pend.imgOut = imgOut;
-        b->pend.totalWeights = totalWeights;
-        return MFSR_OK;
-    }
-    return accumulate_frames(b, 1, slot, -1, raw, nullptr, flow, nullptr, mask, nullptr, imgOut, totalWeights, stream);
+    if (b->pend.n && (b->pend.imgOut != imgOut || b->pend.totalWeights != totalWeights)) TRY(flush_pending(b, stream));
+    const int i = b->pend.n++;
+    b->pend.slot[i] = slot;
+    b->pend.raw[i] = raw;
+    b->pend.flow[i] = flow;
+    b->pend.mask[i] = mask;
+    b->pend.imgOut = imgOut;
+    b->pend.totalWeights = totalWeights;
+    if (b->pend.n < b->group) return MFSR_OK;  // the group is fused when its last frame arrives (or on flush / finish)
+    return accumulate_pending(b, stream);
+}
+
+extern "C" int mfsr_burst_group_size(const mfsr_config* cfg)
+{
+    if (!cfg || cfg->pairFrames <= 0) return 1;
+    if (cfg->pairFrames >= 2) return cfg->pairFrames < MFSR_MAX_FUSE_GROUP ? cfg->pairFrames : MFSR_MAX_FUSE_GROUP;
+    // as many as one launch takes: the x2 Bayer tile kernel fuses four, every other geometry two
+    return (cfg->scale == 2 && !cfg->mono) ? MFSR_MAX_FUSE_GROUP : 2;
 }
 
 // ---- building blocks of stripe-sharded bursts (multi-GPU: frames are aligned where they live, every rank fuses ALL
@@ -922,14 +924,14 @@ extern "C" int mfsr_burst_fuse_rows(mfsr_burst* b, int nFrames, const uint16_t* 
                                     mfsr_float3* totalWeights, int accumulatorsUndefined, int rowBegin, int rowEnd,
                                     mfsr_stream_t stream)
 {
-    MFSR_REQUIRE(b && raws && flows && masks && imgOut && totalWeights && nFrames >= 1 && nFrames <= 2);
+    MFSR_REQUIRE(b && raws && flows && masks && imgOut && totalWeights && nFrames >= 1 && nFrames <= MFSR_MAX_FUSE_GROUP);
     MFSR_REQUIRE(b->haveRef);
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
     const mfsr_float3 white = {c.white[0], c.white[1], c.white[2]};
     const mfsr_float3 black = {c.black[0], c.black[1], c.black[2]};
     TRY(mfsr_set_cfa_pattern(c.cfa));
-    mfsr_tex2d sh[2];
+    mfsr_tex2d sh[MFSR_MAX_FUSE_GROUP];
     for (int n = 0; n < nFrames; n++) {
         sh[n].ptr = flows[n];
         sh[n].pitch = flowPitch;
@@ -1092,6 +1094,12 @@ extern "C" int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw,
     if (isReference && hostRaw == b->refHost && b->refDev)
         return mfsr_burst_add_frame(b, b->refDev, 1, imgOut, totalWeights, stream);
     const int us = b->upCounter++ % b->cfg.uploadRing;
+    // a ring shorter than the fuse group: the slot may still hold a frame that waits for the rest of its group
+    for (int i = 0; i < b->pend.n; i++)
+        if (b->pend.raw[i] == b->L.rawRing[us]) {
+            TRY(accumulate_pending(b, stream));
+            break;
+        }
     TRY(upload_into(b, us, b->L.rawRing[us], hostRaw, stream));
     return mfsr_burst_add_frame(b, b->L.rawRing[us], isReference, imgOut, totalWeights, stream);
 }
@@ -1144,6 +1152,11 @@ extern "C" int mfsr_burst_process_source(mfsr_burst* b, const mfsr_frame_source*
         } else {
             us = b->upCounter++ % b->cfg.uploadRing;
             dst = b->L.rawRing[us];
+            for (int i = 0; i < b->pend.n; i++)  // a ring shorter than the fuse group (see mfsr_burst_add_frame_host)
+                if (b->pend.raw[i] == dst) {
+                    TRY(accumulate_pending(b, stream));
+                    break;
+                }
         }
         if (b->freeRecorded[us]) {
             MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evFree[us], 0));

@@ -226,7 +226,7 @@ def process_burst_stripes(pipe, frames, bufs: Optional[StripeBuffers] = None, gr
     if mine.rowEnd > mine.rowBegin:
         for k in range(n if mine.rawRows < pipe.cfg.height else 0):   # a whole-frame halo needs no check
             pipe.check_flow_bound(bufs.flow[k][mine.flowRow0:mine.flowRow0 + mine.flowRows], float(mine.maxFlowY), bufs.flag)
-        per = 2 if pipe.cfg.pairFrames else 1
+        per = pipe.group_size()   # the grouping of the single-GPU burst: same sums in the same order
         for k in range(0, n, per):
             ks = list(range(k, min(k + per, n)))
             pipe.fuse_rows([raws[j] for j in ks], [bufs.flow[j] for j in ks], [bufs.mask[j] for j in ks], mine.rowBegin,

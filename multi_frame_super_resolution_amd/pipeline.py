@@ -162,6 +162,10 @@ class BurstPipeline:
         self.L.burst_align_frame(self._h, raw.data_ptr(), 1 if is_reference else 0, flow.data_ptr(), flow.stride(0) * 4,
                                  mask.data_ptr(), mask.stride(0) * 4, self._stream())
 
+    def group_size(self) -> int:
+        """Frames per warp+fuse launch cfg.pairFrames stands for (mfsr_burst_group_size)."""
+        return int(self.L.raw["mfsr_burst_group_size"](ctypes.byref(self.cfg)))
+
     def fuse_rows(self, raws, flows, masks, row_begin: int, row_end: int, fresh: bool):
         n = len(raws)
         P = ctypes.c_void_p * n

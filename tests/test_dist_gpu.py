@@ -75,8 +75,9 @@ def test_virtual_rank_stripes_equal_single_gpu(W, H, N, scale, mono, worlds):
             assert int(flag.item()) == 0
             pipe._img_out.fill_(float("nan"))       # fresh mode must not read them
             pipe._total_weights.fill_(float("nan"))
-            for k in range(0, N, 2):
-                ks = list(range(k, min(k + 2, N)))
+            per = pipe.group_size()   # the single-GPU burst's grouping: same sums in the same order
+            for k in range(0, N, per):
+                ks = list(range(k, min(k + per, N)))
                 pipe.fuse_rows([raws[j] for j in ks], [flows[j] for j in ks], [masks[j] for j in ks], pl.rowBegin, pl.rowEnd, k == 0)
             out = pipe.finish_rows(pl.rowBegin, pl.rowEnd - pl.rowBegin)
             got[pl.rowBegin:pl.rowEnd] = out[pl.rowBegin:pl.rowEnd]

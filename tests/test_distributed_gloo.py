@@ -89,6 +89,11 @@ class OracleStripePipe(OraclePipe):
             self.img_out[row_begin:row_end] = torch.from_numpy(a[row_begin:row_end])
             self.total_weights[row_begin:row_end] = torch.from_numpy(w[row_begin:row_end])
 
+    def group_size(self):
+        import ctypes
+        from multi_frame_super_resolution_amd import capi
+        return int(capi.lib().raw["mfsr_burst_group_size"](ctypes.byref(self.cfg)))
+
     def check_flow_bound(self, flow_rows, bound, flag):
         if not bool((flow_rows[..., 1].abs() <= bound).all()):
             flag |= 1

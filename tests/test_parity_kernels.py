@@ -243,6 +243,59 @@ def test_accumulate_x2_two_frames_per_call(orc, hip, pat, field):
     assert np.abs(hw_).max() > 0.5
 
 
+@pytest.mark.parametrize("fresh", [0, 1])
+@pytest.mark.parametrize("n,field,s,pat", [(3, "quarter", 2, "RGGB"), (4, "quarter", 2, "RGGB"), (4, "quarter", 2, "GBRG"),
+                                           (4, "quarter", 2, "MONO"), (3, "half", 2, "RGGB"), (4, "quarter", 4, "RGGB")])
+def test_accumulate_groups_of_three_and_four(orc, hip, n, field, s, pat, fresh):
+    """mfsr_accumulateSuperResFullN with 3 / 4 frames == that many oracle calls in the same order.  x2 with quarter-resolution
+    fields: ONE launch of the LDS tile kernel (pixel-major, tap weights once per pixel, one plane-set staged at a time)
+    plus one margin launch; the other geometries split the group.  fresh: the accumulators hold garbage and are overwritten."""
+    import torch
+    W, H = 328, 104   # ragged: the last 256-pixel tile is partial; rows not a multiple of 16
+    cfa = [1, 1, 1, 1] if pat == "MONO" else PATTERNS[pat]
+    orc.set_cfa(cfa)
+    hip.set_cfa(cfa)
+    white, black = F3([3839, 3700, 3900]), F3([256, 260, 250])
+    fh, fw = {"quarter": (H // 2, W // 2), "half": (H, W)}[field]
+    if s == 4:
+        fh, fw = H // 2, W // 2
+    kp = _kernel_field(170, fh, fw, 4)
+    yy, xx = np.mgrid[0:fh, 0:fw].astype(np.float32)
+    frames = []
+    for k in range(n):
+        raw, _, _, mask = _accum_inputs(171 + k, W, H, W * s, H * s, nan_frac=0.01)
+        sh = np.stack([1.3 - 0.9 * k + 0.01 * xx, -2.2 + 1.1 * k + 0.02 * yy], -1).astype(np.float32)
+        if k == 0:
+            sh[10:14, 10:14] = 1e9      # wild patch: these strips take the straight arithmetic inside the tile kernel
+        if k == n - 1:
+            sh[20, 20] = np.nan
+        frames.append((raw, mask, np.ascontiguousarray(sh)))
+    _, oi, ow, _ = _accum_inputs(199, W, H, W * s, H * s, nan_frac=0.0)
+    hi0, hw0 = oi.copy(), ow.copy()
+    if fresh:
+        oi[:] = 0
+        ow[:] = 0
+    for raw, m, sh in frames:
+        orc.call("accumulateSuperResFull", raw, oi, ow, m, Tex(kp), Tex(sh), white, black, W, H, s, pitch_of(oi), pitch_of(m))
+    dev = hip.dev
+    d_raw = [torch.from_numpy(f[0].view(np.int16)).to(dev) for f in frames]
+    d_mask = [torch.from_numpy(f[1]).to(dev) for f in frames]
+    d_sh = [torch.from_numpy(f[2]).to(dev) for f in frames]
+    d_kp = torch.from_numpy(kp).to(dev)
+    d_i, d_w = torch.from_numpy(hi0).to(dev), torch.from_numpy(hw0).to(dev)
+    P = ctypes.c_void_p * n
+    T = hip.capi.Tex2D * n
+    shs = T(*[hip.capi.Tex2D(t.data_ptr(), fw * 8, fw, fh) for t in d_sh])
+    hip.L.accumulateSuperResFullN(n, P(*[t.data_ptr() for t in d_raw]), d_i.data_ptr(), d_w.data_ptr(),
+                                  P(*[t.data_ptr() for t in d_mask]), hip.capi.Tex2D(d_kp.data_ptr(), fw * 16, fw, fh), shs,
+                                  hip.capi.f3(white.v), hip.capi.f3(black.v), W, H, s, pitch_of(oi), pitch_of(frames[0][1]), fresh, None)
+    torch.cuda.synchronize()
+    hi, hw_ = d_i.cpu().numpy(), d_w.cpu().numpy()
+    np.testing.assert_allclose(hw_, ow, rtol=3e-5, atol=3e-5)
+    np.testing.assert_allclose(hi, oi, rtol=3e-5, atol=3e-5)
+    assert np.abs(hw_).max() > 0.5
+
+
 @pytest.mark.parametrize("s", [2, 4])
 def test_accumulate_anisotropic_kernels(orc, hip, s):
     """Kernel parameters as ComputeKernelParam makes them at strong edges: inverse covariances with

@@ -176,10 +176,10 @@ def test_full_size_properties_4k():
     pipe.close()
 
 
-def test_frame_pairing_equals_frame_by_frame():
-    """cfg.pairFrames (two frames per pass over the accumulators, the default) against one launch per
-    frame: same u16 image up to the re-association of the two per-pixel sums; an odd burst leaves the
-    last frame to flush/finish."""
+def test_frame_grouping_equals_frame_by_frame():
+    """cfg.pairFrames (1, the default: four frames per pass over the accumulators at x2 Bayer; 2 and 3: that many)
+    against one launch per frame: same u16 image up to the re-association of the per-pixel sums; a burst that is
+    not a multiple of the group leaves the rest to flush/finish."""
     import torch
     from multi_frame_super_resolution_amd import synth
     from multi_frame_super_resolution_amd.pipeline import BurstPipeline, default_config
@@ -187,17 +187,19 @@ def test_frame_pairing_equals_frame_by_frame():
     W, H, N = 384, 256, 5
     frames, _, _ = synth.make_burst(W, H, N, seed=11, device=dev)
     outs = {}
-    for pair in (0, 1):
+    for pair in (0, 1, 2, 3):
         cfg = default_config(W, H, N, scale=2)
         assert cfg.pairFrames == 1
         cfg.pairFrames = pair
         pipe = BurstPipeline(cfg, dev)
+        assert pipe.group_size() == {0: 1, 1: 4, 2: 2, 3: 3}[pair]
         _, o16 = pipe.process(frames)
         outs[pair] = (o16.cpu().numpy().view(np.uint16).astype(np.int32), pipe.total_weights.cpu().numpy())
         pipe.close()
-    d = np.abs(outs[0][0] - outs[1][0])
-    assert d.max() <= 1 and (d > 0).mean() < 1e-3
-    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=2e-5, atol=2e-5)
+    for pair in (1, 2, 3):
+        d = np.abs(outs[0][0] - outs[pair][0])
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3, pair   # 16-bit LSB flips of the re-associated sums
+        np.testing.assert_allclose(outs[0][1], outs[pair][1], rtol=2e-5, atol=2e-5)
 
 
 def test_async_fuse_is_bit_identical():
