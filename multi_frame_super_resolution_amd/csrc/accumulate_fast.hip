@@ -601,7 +601,14 @@ __global__ void __launch_bounds__(256)
 #ifndef TILE_WAVES2
 #define TILE_WAVES2 4
 #endif
-#define TILE_WAVES_NF(NF) ((NF) == 1 ? TILE_WAVES : TILE_WAVES2)
+// Three and four frames per launch: both plane-sets staged (43 / 48 KiB of LDS: three workgroups per CU, so the register
+// budget is 168) or one at a time (31 / 36 KiB: four workgroups, 128 registers).  Measured at 4K x 16, four frames per
+// launch: 1.004 ms with both (no spills) against 1.044 - 1.068 ms with one (10 spilled registers and the second plane-set's
+// load exposed) -- both is the default; 0 keeps the other form for A/B.
+#ifndef TILE_GROUP_BOTH_PLANES
+#define TILE_GROUP_BOTH_PLANES 1
+#endif
+#define TILE_WAVES_NF(NF) ((NF) == 1 ? TILE_WAVES : ((NF) > 2 && TILE_GROUP_BOTH_PLANES) ? 3 : TILE_WAVES2)
 // two frames per launch: pixel-major order with the tap weights shared by both frames (0: frame-major, weights per frame)
 #ifndef TILE_PIXEL_MAJOR
 #define TILE_PIXEL_MAJOR 1
@@ -633,9 +640,9 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     __shared__ __attribute__((aligned(16))) float sColA[256];  // x fraction per HR column of the tile, -1 = not on the predicted texel
     __shared__ float sRowB[4];                                 // y fraction per HR row of the tile, -1 likewise
     // accumulator staging: per wave and plane-set the wave's 3 KiB row segment, in memory order
-    // (three and four frames per launch: one plane-set at a time through the same 3 KiB, or four workgroups per CU would
-    // not fit the 160 KiB -- the pixel sums wait in registers, the second plane-set's load is the only exposed latency)
-    constexpr int PL = NF <= 2 ? 2 : 1;
+    // (TILE_GROUP_BOTH_PLANES = 0, three and four frames per launch: one plane-set at a time through the same 3 KiB so that
+    // four workgroups per CU fit the 160 KiB -- the weight sums wait in registers, the second plane-set's load is exposed)
+    constexpr int PL = (NF <= 2 || TILE_GROUP_BOTH_PLANES) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float4 sAcc[4][PL][192];
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int tx = bIdX * 64 + lx;
@@ -795,6 +802,10 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
         auto pixel = [&](auto kc) {
             constexpr int k = decltype(kc)::value;
             if (safeBits == 0) return;
+            // this pixel's value sums live here only while the pixel is worked on, then go into the staged plane-set
+            // (12 registers fewer across the other pixels; the weight sums have no staged plane yet when NF > 2)
+            float aP[12];
+            aP[3 * k] = aP[3 * k + 1] = aP[3 * k + 2] = 0.0f;
             float w[13];
             tap_weights13(kxa[k], kya[k], kza[k], w);
 #pragma unroll
@@ -811,9 +822,14 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
                     };
                     auto mval = [&](int jt, int cell, int e) { return mrow[jt][n * (3 * TILE_COLS * 4) + cell * 4 + e]; };
                     const int sx = (int)(int16_t)(sxy[n][k] & 0xffffu), sy = (int)sxy[n][k] >> 16;
-                    strip_pixel_w<k, CFA, true>(X0 + k, Y, sx, sy, w, rawf, mval, lv, accP, accW);
+                    strip_pixel_w<k, CFA, true>(X0 + k, Y, sx, sy, w, rawf, mval, lv, aP, accW);
                 }
             }
+            if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged plane-set has landed (long ago)
+            float* myP = (float*)&sAcc[ly][0][0] + lx * 12 + 3 * k;
+            myP[0] += aP[3 * k];
+            myP[1] += aP[3 * k + 1];
+            myP[2] += aP[3 * k + 2];
         };
         pixel(std::integral_constant<int, 0>{});
         pixel(std::integral_constant<int, 1>{});
@@ -940,14 +956,15 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     using No = std::false_type;
     // staged accumulators must have landed before anyone reads them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr bool valueSumsStaged = TILE_PIXEL_MAJOR && NF > 1;  // the pixel-major loop has added them already
     if constexpr (PL == 2) {
-        add_plane(0, accP);
+        if (!valueSumsStaged) add_plane(0, accP);
         add_plane(1, accW);
         if (safeBits != (1u << NF) - 1u) slow_frames(Yes{}, Yes{}, 0, 1);
         store_plane(0, gP);
         store_plane(1, gW);
     } else {
-        add_plane(0, accP);
+        if (!valueSumsStaged) add_plane(0, accP);
         if (safeBits != (1u << NF) - 1u) slow_frames(Yes{}, No{}, 0, 0);
         store_plane(0, gP);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // plane 0 has been read out before the copy overwrites it

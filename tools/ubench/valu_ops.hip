@@ -45,6 +45,15 @@ __global__ void __launch_bounds__(256) k(float* out, int iters)
         if (KIND == 29) { REP16(asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a), "v"(b) : "s4");) }
         if (KIND == 30) { REP16(asm volatile("v_mov_b32 %0, %4\n v_mov_b32 %1, %4\n v_mov_b32 %2, %4\n v_mov_b32 %3, %4" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a), "v"(b) : "s4");) }
         if (KIND == 31) { REP16(asm volatile("v_cvt_f32_u32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_u32_sdwa %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_u32_sdwa %2, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_u32_sdwa %3, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a), "v"(b) : "s4");) }
+        if (KIND == 40) { REP16(asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a));) }
+        if (KIND == 41) { REP16(asm volatile("v_mad_i64_i32 %0, s[20:21], %4, %4, %0\n v_mad_i64_i32 %1, s[20:21], %4, %4, %1\n v_mad_i64_i32 %2, s[20:21], %4, %4, %2\n v_mad_i64_i32 %3, s[20:21], %4, %4, %3" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(a) : "s20", "s21");) }
+        if (KIND == 42) { REP16(asm volatile("v_lshl_add_u64 %0, %0, 1, %4\n v_lshl_add_u64 %1, %1, 1, %4\n v_lshl_add_u64 %2, %2, 1, %4\n v_lshl_add_u64 %3, %3, 1, %4" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(qa));) }
+        if (KIND == 43) { REP16(asm volatile("v_div_scale_f32 %0, vcc, %0, %4, %0\n v_div_scale_f32 %1, vcc, %1, %4, %1\n v_div_scale_f32 %2, vcc, %2, %4, %2\n v_div_scale_f32 %3, vcc, %3, %4, %3" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a) : "vcc");) }
+        if (KIND == 44) { REP16(asm volatile("v_div_fixup_f32 %0, %0, %4, %5\n v_div_fixup_f32 %1, %1, %4, %5\n v_div_fixup_f32 %2, %2, %4, %5\n v_div_fixup_f32 %3, %3, %4, %5" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a), "v"(b));) }
+        if (KIND == 45) { REP16(asm volatile("v_div_fmas_f32 %0, %0, %4, %5\n v_div_fmas_f32 %1, %1, %4, %5\n v_div_fmas_f32 %2, %2, %4, %5\n v_div_fmas_f32 %3, %3, %4, %5" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a), "v"(b) : "vcc");) }
+        if (KIND == 46) { REP16(asm volatile("v_mul_u32_u24 %0, %0, %4\n v_mul_u32_u24 %1, %1, %4\n v_mul_u32_u24 %2, %2, %4\n v_mul_u32_u24 %3, %3, %4" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a));) }
+        if (KIND == 47) { REP16(asm volatile("v_min_i32 %0, %0, %4\n v_min_i32 %1, %1, %4\n v_min_i32 %2, %2, %4\n v_min_i32 %3, %3, %4" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a));) }
+        if (KIND == 48) { REP16(asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));) }
         if (KIND == 7) { REP16(asm volatile("v_cvt_f32_u32 %0, %0\n v_cvt_f32_u32 %1, %1\n v_cvt_f32_u32 %2, %2\n v_cvt_f32_u32 %3, %3" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));) }
     }
     out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + q0.x + q0.y + q1.x + q1.y + q2.x + q2.y + q3.x + q3.y;
@@ -91,6 +100,8 @@ int main()
         run<29>("v_rcp_f32", d);
         run<30>("v_mov_b32", d);
         run<31>("v_cvt_f32_u32_sdwa", d);
+        run<40>("v_mul_lo_u32", d); run<41>("v_mad_i64_i32", d); run<42>("v_lshl_add_u64", d); run<43>("v_div_scale_f32", d);
+        run<44>("v_div_fixup_f32", d); run<45>("v_div_fmas_f32", d); run<46>("v_mul_u32_u24", d); run<47>("v_min_i32", d); run<48>("v_sqrt_f32", d);
         run<8>("v_pk_fma_f32", d); run<9>("v_pk_mul_f32", d); run<10>("v_pk_add_f32", d); run<11>("mixed sub/mul/fma/add", d);
     }
     return 0;
