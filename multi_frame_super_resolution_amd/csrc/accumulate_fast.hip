@@ -377,21 +377,25 @@ struct TileFrames {
     TileFrame f[NF];
 };
 
-// the margin pixels of NF frames in one launch: the accumulators of a pixel are read and written once, its frames add in
-// call order (the same sums, in the same order, as NF launches of k_accumulateMargin)
+// the margin pixels of NF frames in one launch.  The straight arithmetic is a chain of dependent loads (flow, kernel
+// parameters, then raw and certainty per tap) on 7.6 K wavefronts at 4K: one thread per (pixel, frame) -- 64 pixels x NF
+// frames per workgroup -- keeps the chain one frame long; the frames' sums (each taken from zero) meet in LDS and are
+// added to the accumulators in call order by the pixel's first thread, which reads and writes them once.
 template <int NF>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * NF)
     k_accumulateMarginN(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
                         Levels3 glv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int scale, int rowBegin,
                         int rowEnd)
 {
+    __shared__ float sSum[NF][6][64];
     const int hrW = scale * dimX, hrH = scale * dimY, M = STRIP_MARGIN;
     const int rowLen = hrW - 2;
     const int nTop = (M - 1) * rowLen, nBot = (M - 1) * rowLen;
     const int sideLen = 2 * (M - 1);
     const int nSide = (hrH - 2 * M) * sideLen;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    int x, y;
+    const int lane = threadIdx.x, n = threadIdx.y;
+    const int idx = blockIdx.x * 64 + lane;
+    int x = 0, y = -1;
     if (idx < nTop) {
         y = 1 + idx / rowLen;
         x = 1 + idx % rowLen;
@@ -404,18 +408,39 @@ __global__ void __launch_bounds__(256)
         y = M + r / sideLen;
         const int c = r % sideLen;
         x = c < M - 1 ? 1 + c : hrW - M + (c - (M - 1));
-    } else {
-        return;
     }
-    if (y < rowBegin || y >= rowEnd) return;
-    pix3 pixel = row_ptr(imgOut, strideOut, y)[x];
-    pix3 totalWeight = row_ptr(totalWeights, strideOut, y)[x];
+    const bool live = y >= rowBegin && y < rowEnd && y >= 0;
+    pix3 pixel = {0.0f, 0.0f, 0.0f}, totalWeight = {0.0f, 0.0f, 0.0f};
+    if (live) {
+        TileFrame F = fr.f[0];
 #pragma unroll
-    for (int n = 0; n < NF; n++)
-        accumulate_pixel_core<GEOM_FULL, true>(x, y, fr.f[n].raw, fr.f[n].mask, kernelParam, fr.f[n].shifts, glv, dimX, dimY, scale,
-                                               strideMask, cfaPacked, pixel, totalWeight);
-    row_ptr(imgOut, strideOut, y)[x] = pixel;
-    row_ptr(totalWeights, strideOut, y)[x] = totalWeight;
+        for (int m = 1; m < NF; m++)
+            if (n == m) F = fr.f[m];
+        accumulate_pixel_core<GEOM_FULL, true>(x, y, F.raw, F.mask, kernelParam, F.shifts, glv, dimX, dimY, scale, strideMask, cfaPacked,
+                                               pixel, totalWeight);
+    }
+    sSum[n][0][lane] = pixel.x;
+    sSum[n][1][lane] = pixel.y;
+    sSum[n][2][lane] = pixel.z;
+    sSum[n][3][lane] = totalWeight.x;
+    sSum[n][4][lane] = totalWeight.y;
+    sSum[n][5][lane] = totalWeight.z;
+    __syncthreads();
+    if (n == 0 && live) {
+        pix3 a = row_ptr(imgOut, strideOut, y)[x];
+        pix3 w = row_ptr(totalWeights, strideOut, y)[x];
+#pragma unroll
+        for (int m = 0; m < NF; m++) {
+            a.x += sSum[m][0][lane];
+            a.y += sSum[m][1][lane];
+            a.z += sSum[m][2][lane];
+            w.x += sSum[m][3][lane];
+            w.y += sSum[m][4][lane];
+            w.z += sSum[m][5][lane];
+        }
+        row_ptr(imgOut, strideOut, y)[x] = a;
+        row_ptr(totalWeights, strideOut, y)[x] = w;
+    }
 }
 
 // one frame of one strip on the register-resident accumulators (k_accumulate2xStrip)
@@ -1491,7 +1516,7 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
                              rowBlock0);
         const int M = STRIP_MARGIN;
         const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
-        hipLaunchKernelGGL(k_accumulateMarginN<NF>, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, mst, fr, pI, pT, kernelParam, glv, dimX,
+        hipLaunchKernelGGL(k_accumulateMarginN<NF>, dim3(mfsr_cdiv(cnt, 64)), dim3(64, NF), 0, mst, fr, pI, pT, kernelParam, glv, dimX,
                            dimY, strideOut, strideMask, cp, 2, rowBegin, rowEnd);
         if (msx) {
             (void)hipEventRecord(msx->join, msx->stream);
