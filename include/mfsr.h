@@ -380,6 +380,20 @@ int mfsr_trackTilesFusedUp(const float* refImg, const float* movedImg, const mfs
 /* mfsr_CreateFlowFieldFromTiles (opticalFlow.cu:48) with baseShift / baseRotation taken from *base (device) */
 int mfsr_CreateFlowFieldFromTilesBase(mfsr_float2* outImg, mfsr_tex2d texObjShiftXY, int imgWidth, int imgHeight,
                                       int imgPitch, const mfsr_prealign* base, mfsr_stream_t stream);
+/* The same iteration with the warped moved image handed over between launches instead of re-gathered for every tile halo:
+ * sumIn / diffIn = (warped + ref) / (warped - ref) of every pixel under shiftsIn (made by mfsr_CreateFlowFieldWarped or by
+ * the previous call's sumOut / diffOut); sumOut / diffOut (both NULL on the last iteration) receive them under shiftsOut,
+ * taken by the thread that has just updated the pixel.  Bit-identical to mfsr_lucasKanadeIterationFused. */
+int mfsr_lucasKanadeIterationWarped(const mfsr_float2* shiftsIn, mfsr_float2* shiftsOut, int pitchShift, const float* refImg,
+                                    const float* movedImg, int pitchImg, const float* sumIn, const float* diffIn, float* sumOut,
+                                    float* diffOut, int pitchSD, int width, int height, int halfWindowSize, float minDet,
+                                    float outScale, mfsr_stream_t stream);
+/* D1 (mfsr_CreateFlowFieldFromTiles; base != NULL: mfsr_CreateFlowFieldFromTilesBase) + the warp of every pixel under the flow
+ * it writes: outImg and the first iteration's sumIn / diffIn in one launch (opticalFlow.cu:48 + :28) */
+int mfsr_CreateFlowFieldWarped(mfsr_float2* outImg, mfsr_tex2d texObjShiftXY, int imgWidth, int imgHeight, int imgPitch,
+                               mfsr_float2 baseShift, float baseRotation, const mfsr_prealign* base, const float* refImg,
+                               const float* movedImg, int pitchImg, float* sumOut, float* diffOut, int pitchSD,
+                               mfsr_stream_t stream);
 
 /* mfsr_finishFused on rows [rowOffset, rowOffset + height) of a fullHeight-row image (pointers = first row of the stripe;
  * u/v window = that of the WHOLE image): bit-identical to the rows of the whole-image call */

@@ -197,7 +197,7 @@ __device__ __forceinline__ void tap_weights13(float kx, float ky, float kz, floa
 //    four values instead of one select per tap;
 //  * exponents from pre-scaled sums: 2 adds per weight instead of mul+2 adds+mul.
 // ~245 VALU instructions per pixel instead of ~330; sums re-associated again (fma), same tolerance.
-// PARITY = true (the LDS tile kernel): mval(jt, cell, e) returns the certainty of the colour at CFA position e =
+// PARITY = true (the LDS tile kernel): mval(jt, cell, 4 * e) returns the certainty of the colour at CFA position e =
 // (y parity << 1) | x parity of mask cell `cell` on tap row jt's mask row -- the certainty texels are staged in LDS in
 // CFA-position order, so "which channel does this site see" is an LDS ADDRESS (a few integer ops per pixel) instead of
 // three v_bitop3 selects per tap row and cell.
@@ -210,8 +210,11 @@ __device__ __forceinline__ void strip_pixel_w(int X, int Y, int sx, int sy, cons
 {
     const int qx = X + sx - 2, qy = Y + sy - 2;
     const int x0 = qx >> 1, y0 = qy >> 1;
-    const uint32_t mbx = 0u - (uint32_t)(qx & 1), mby = 0u - (uint32_t)(qy & 1);
-    const uint32_t nbx = ~mbx, nby = ~mby;
+    uint32_t mbx = 0u - (uint32_t)(qx & 1), mby = 0u - (uint32_t)(qy & 1);
+    uint32_t nbx = ~mbx, nby = ~mby;
+    // opaque to the compiler: it would turn `weight & mask` into v_cndmask_b32 on the parity bit, which issues at 0.63x
+    // the rate of v_and_b32 on gfx950 (profiles/r02_ubench_valu_ops.txt)
+    asm volatile("" : "+v"(mbx), "+v"(nbx), "+v"(mby), "+v"(nby));
     const uint32_t mP = 0u - (uint32_t)(x0 & 1), mQ = 0u - (uint32_t)(y0 & 1);
     auto andm = [](uint32_t m, float a) { return __uint_as_float(m & __float_as_uint(a)); };
 
@@ -249,13 +252,14 @@ __device__ __forceinline__ void strip_pixel_w(int X, int Y, int sx, int sy, cons
         if constexpr (PARITY) {
             // CFA position of an even site column on this tap row: y parity Q (rows 0, 4), ~Q (row 2), Q ^ by (row 1),
             // ~(Q ^ by) (row 3); x parity P.  Odd site columns: x parity flipped.
-            const int eQ = ((y0 & 1) << 1) | (x0 & 1);
-            const int by2 = (qy & 1) << 1;
-            const int e = (jt == 0 || jt == 4) ? eQ : (jt == 2 ? (eQ ^ 2) : (jt == 1 ? (eQ ^ by2) : (eQ ^ 2 ^ by2)));
+            // (as byte offsets into the texel: the address is then a plain add)
+            const int eQ = ((qy << 2) & 8) | ((qx + qx) & 4);   // ((y0 & 1) << 1 | (x0 & 1)) * 4 with x0 = qx >> 1, y0 = qy >> 1
+            const int by2 = (qy << 3) & 8;
+            const int e = (jt == 0 || jt == 4) ? eQ : (jt == 2 ? (eQ ^ 8) : (jt == 1 ? (eQ ^ by2) : (eQ ^ 8 ^ by2)));
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 Ee[c] = mval(jt, cellLo + c, e);
-                Eo[c] = mval(jt, cellLo + c, e ^ 1);
+                Eo[c] = mval(jt, cellLo + c, e ^ 4);
             }
         } else {
 #pragma unroll
@@ -845,7 +849,9 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
                             for (int i = 0; i < 3; i++) sv[j][i] = (float)*(const uint16_t*)(rb + 2 * i);
                         }
                     };
-                    auto mval = [&](int jt, int cell, int e) { return mrow[jt][n * (3 * TILE_COLS * 4) + cell * 4 + e]; };
+                    auto mval = [&](int jt, int cell, int e4) {
+                        return *(const float*)((const char*)(mrow[jt] + n * (3 * TILE_COLS * 4) + cell * 4) + e4);
+                    };
                     const int sx = (int)(int16_t)(sxy[n][k] & 0xffffu), sy = (int)sxy[n][k] >> 16;
                     strip_pixel_w<k, CFA, true>(X0 + k, Y, sx, sy, w, rawf, mval, lv, aP, accW);
                 }
@@ -911,10 +917,9 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
 #pragma unroll
             for (int k = 0; k < 4; k++) asm volatile("" : "+v"(kxa[k]), "+v"(kya[k]), "+v"(kza[k]));
             // certainty: LDS row of the mask row that tap row jt reads = ((ly + jt - 2) >> 2) + 1; column lx + cell
-            auto mval = [&](int jt, int cell, int e) {
+            auto mval = [&](int jt, int cell, int e4) {
                 const int mr = ((ly + jt - 2) >> 2) + 1;
-                const float* p = (const float*)&sM[n][mr][lx + cell];
-                return p[e];
+                return *(const float*)((const char*)&sM[n][mr][lx + cell] + e4);
             };
             strip_pixel<0, CFA, true>(X0 + 0, Y, sx[0], sy[0], kxa[0], kya[0], kza[0], raw, dimX, mval, lv, accP, accW);
             strip_pixel<1, CFA, true>(X0 + 1, Y, sx[1], sy[1], kxa[1], kya[1], kza[1], raw, dimX, mval, lv, accP, accW);

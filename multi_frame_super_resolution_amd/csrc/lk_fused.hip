@@ -28,6 +28,7 @@
 //
 // Flow is double-buffered (shiftsIn -> shiftsOut): the halo of a tile reads
 // flow values owned by other workgroups, so an in-place update would race.
+#include <cstdlib>
 #include "common.hpp"
 #include "lk_math.hpp"
 
@@ -45,13 +46,49 @@ __device__ __forceinline__ int lk_mirror_index(int i, int n)
     return i >= n ? 2 * n - 1 - i : i;
 }
 
+// warped moved image and reference at pixel (gx, gy) (inside the image) under flow f: opticalFlow.cu:28-44.
+// Interior samples (0 <= u,v < 1, both texel pairs inside the image): mirror_coord is the identity and no index is
+// clamped, so the fetch is four plain loads with the very same arithmetic as tex1<ADDR_MIRROR>; the few other samples
+// are redone with the full addressing (wave-uniform branch: only waves that touch the image border pay for it).
+__device__ __forceinline__ void lk_warp_sample(const float* __restrict__ refImg, const float* __restrict__ movedImg, int pitchImg,
+                                               int width, int height, int gx, int gy, float2 f, float& wv, float& rv)
+{
+    rv = row_ptr(refImg, pitchImg, gy)[gx];
+    const float u = ((float)gx + 0.5f + f.x) / (float)width;   // opticalFlow.cu:38-39
+    const float v = ((float)gy + 0.5f + f.y) / (float)height;
+    const float xB = u * (float)width - 0.5f, yB = v * (float)height - 0.5f;
+    const float fx = floorf(xB), fy = floorf(yB);
+    const int ix = f2i(fx), iy = f2i(fy);
+    const bool interior = u >= 0.0f && u < 1.0f && v >= 0.0f && v < 1.0f && (uint32_t)ix <= (uint32_t)(width - 2) &&
+                          (uint32_t)iy <= (uint32_t)(height - 2);
+    const int ixc = clampi(ix, 0, width - 2), iyc = clampi(iy, 0, height - 2);
+    const float* r0 = row_ptr(movedImg, pitchImg, iyc) + ixc;
+    const float* r1 = row_ptr(movedImg, pitchImg, iyc + 1) + ixc;
+    wv = lerp4(r0[0], r0[1], r1[0], r1[1], xB - fx, yB - fy);
+    if (__ballot(!interior) != 0) {
+        mfsr_tex2d texMoved;
+        texMoved.ptr = movedImg;
+        texMoved.pitch = pitchImg;
+        texMoved.width = width;
+        texMoved.height = height;
+        const float full = tex1<ADDR_MIRROR>(texMoved, u, v);
+        wv = interior ? wv : full;
+    }
+}
+
 // HT > 0: half window size known at compile time (tile geometry becomes constant, so the
 // index arithmetic of the staging loops needs no runtime integer division); HT == 0: runtime h.
-template <int HT, int LK_TX>
+// PRE: the warped moved image enters as two images made by the PREVIOUS launch -- sumIn = warped + ref, diffIn = warped - ref
+// at every pixel (mfsr_CreateFlowFieldWarped before the first iteration, this kernel's own epilogue afterwards) -- and the
+// tile + halo is loaded instead of warped: every pixel is warped once per iteration, by the thread that has just updated
+// its flow, instead of 1.96 times (tile + halo of a 48 x 16 tile with h = 3).  Same samples, same arithmetic, same bits.
+template <int HT, int LK_TX, bool PRE = false>
 __global__ void __launch_bounds__(LK_TX * LK_TY)
     k_lkIterationFused(const float2* __restrict__ shiftsIn, float2* __restrict__ shiftsOut, int pitchShift,
                        const float* __restrict__ refImg, const float* __restrict__ movedImg, int pitchImg, int width,
-                       int height, int hRuntime, float minDet, float outScale)
+                       int height, int hRuntime, float minDet, float outScale, const float* __restrict__ sumIn = nullptr,
+                       const float* __restrict__ diffIn = nullptr, float* __restrict__ sumOut = nullptr,
+                       float* __restrict__ diffOut = nullptr, int pitchSD = 0)
 {
     constexpr int LK_THREADS = LK_TX * LK_TY;
     const int h = HT > 0 ? HT : hRuntime;
@@ -65,38 +102,23 @@ __global__ void __launch_bounds__(LK_TX * LK_TY)
     const int x0 = blockIdx.x * LK_TX, y0 = blockIdx.y * LK_TY;
     const int tid = threadIdx.y * LK_TX + threadIdx.x;
 
-    mfsr_tex2d texMoved;
-    texMoved.ptr = movedImg;
-    texMoved.pitch = pitchImg;
-    texMoved.width = width;
-    texMoved.height = height;
-
-    // 1. reference + warped moved image for the tile and its (h+2) halo
-    // Interior samples (0 <= u,v < 1, both texel pairs inside the image): mirror_coord is the identity
-    // and no index is clamped, so the fetch is four plain loads with the very same arithmetic as
-    // tex1<ADDR_MIRROR>; the few other samples are redone with the full addressing.  With the trip
-    // count known (HT > 0) the rounds are unrolled so that the loads of all rounds are in flight together.
+    // 1. reference + warped moved image for the tile and its (h+2) halo.  With the trip count known (HT > 0) the rounds
+    // are unrolled so that the loads of all rounds are in flight together.
     auto warp_one = [&](int i, bool active) {
         const int ly = i / BW, lx = i - ly * BW;
         const int gx = lk_mirror_index(x0 + lx - h - 2, width);
         const int gy = lk_mirror_index(y0 + ly - h - 2, height);
-        const float2 f = row_ptr(shiftsIn, pitchShift, gy)[gx];
-        const float rv = row_ptr(refImg, pitchImg, gy)[gx];
-        const float u = ((float)gx + 0.5f + f.x) / (float)width;   // opticalFlow.cu:38-39
-        const float v = ((float)gy + 0.5f + f.y) / (float)height;
-        const float xB = u * (float)width - 0.5f, yB = v * (float)height - 0.5f;
-        const float fx = floorf(xB), fy = floorf(yB);
-        const int ix = f2i(fx), iy = f2i(fy);
-        const bool interior = u >= 0.0f && u < 1.0f && v >= 0.0f && v < 1.0f && (uint32_t)ix <= (uint32_t)(width - 2) &&
-                              (uint32_t)iy <= (uint32_t)(height - 2);
-        const int ixc = clampi(ix, 0, width - 2), iyc = clampi(iy, 0, height - 2);
-        const float* r0 = row_ptr(movedImg, pitchImg, iyc) + ixc;
-        const float* r1 = row_ptr(movedImg, pitchImg, iyc + 1) + ixc;
-        float wv = lerp4(r0[0], r0[1], r1[0], r1[1], xB - fx, yB - fy);
-        if (__ballot(!interior) != 0) {  // wave-uniform: only waves that touch the image border pay for it
-            const float full = tex1<ADDR_MIRROR>(texMoved, u, v);
-            wv = interior ? wv : full;
+        if (PRE) {
+            const float sv = row_ptr(sumIn, pitchSD, gy)[gx], dv = row_ptr(diffIn, pitchSD, gy)[gx];
+            if (active) {
+                s_ref[i] = sv;
+                s_wrp[i] = dv;
+            }
+            return;
         }
+        const float2 f = row_ptr(shiftsIn, pitchShift, gy)[gx];
+        float wv, rv;
+        lk_warp_sample(refImg, movedImg, pitchImg, width, height, gx, gy, f, wv, rv);
         if (active) {
             // the derivative stencil is linear: keep (warped + ref) for Ix, Iy and (warped - ref) = It
             s_ref[i] = wv + rv;
@@ -207,6 +229,13 @@ __global__ void __launch_bounds__(LK_TX * LK_TY)
                 shift.y += UV1;
             }
         }
+        if (PRE && sumOut) {
+            // the next iteration's input: this pixel warped under its new flow (outScale is 1 on every iteration but the last)
+            float wv, rv;
+            lk_warp_sample(refImg, movedImg, pitchImg, width, height, pxX, pxY, shift, wv, rv);
+            row_ptr(sumOut, pitchSD, pxY)[pxX] = wv + rv;
+            row_ptr(diffOut, pitchSD, pxY)[pxX] = wv - rv;
+        }
         // outScale != 1 on the last iteration of a pipeline whose tracking image is smaller than the raw
         // frame: the flow leaves in raw-pixel units without a separate scaling pass (x1 is exact)
         shift.x *= outScale;
@@ -231,9 +260,11 @@ __global__ void __launch_bounds__(LK_TX * LK_TY)
     }
 }
 
-extern "C" int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_float2* shiftsOut, int pitchShift,
-                                              const float* refImg, const float* movedImg, int pitchImg, int width,
-                                              int height, int halfWindowSize, float minDet, float outScale, mfsr_stream_t stream)
+template <bool PRE>
+static int lk_iteration_impl(const mfsr_float2* shiftsIn, mfsr_float2* shiftsOut, int pitchShift, const float* refImg,
+                             const float* movedImg, int pitchImg, int width, int height, int halfWindowSize, float minDet,
+                             float outScale, const float* sumIn, const float* diffIn, float* sumOut, float* diffOut, int pitchSD,
+                             mfsr_stream_t stream)
 {
     MFSR_REQUIRE(shiftsIn && shiftsOut && shiftsIn != shiftsOut && refImg && movedImg && width > 0 && height > 0);
     MFSR_REQUIRE(halfWindowSize >= 0 && halfWindowSize <= 15);
@@ -244,7 +275,18 @@ extern "C" int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_
     // TX is a template parameter of the kernel: 48 only for the half-window sizes that have a <h,48>
     // instantiation below (1..7); every other size runs the generic <0,32> kernel
     const bool hasWide = h >= 1 && h <= 7;
-    const int TX = (hasWide && width >= 48 + 2 * h + 4) ? 48 : 32;
+    static const int forceTx = [] {
+        const char* e = getenv("MFSR_LK_TX");
+        return e ? atoi(e) : 0;
+    }();
+    // tile width: 48 when the kernel warps its tile + halo itself (fewest warps per pixel); 32 when the warped image is
+    // handed in (PRE): the halo is then only loads, and the smaller workgroup (40 KB of LDS, four per CU instead of two)
+    // hides the two global round trips of a tile better -- 6.55 against 6.69 ms per 4K burst; 64 wide: no better.
+    // MFSR_LK_TX=32|48|64 overrides (A/B).
+    int TX = (hasWide && !PRE && width >= 48 + 2 * h + 4) ? 48 : 32;
+    if (forceTx == 32) TX = 32;
+    if (forceTx == 48 && hasWide && width >= 48 + 2 * h + 4) TX = 48;
+    if (PRE && forceTx == 64 && hasWide && width >= 64 + 2 * h + 4) TX = 64;
     const int BW = TX + 2 * h + 4, BH = LK_TY + 2 * h + 4, AW = TX + 2 * h, AH = LK_TY + 2 * h;
     const size_t lds = sizeof(float) * ((size_t)2 * BW * BH + (size_t)5 * AW * AH + (size_t)5 * TX * AH);
     if (lds > 160 * 1024) return MFSR_E_UNSUPPORTED;
@@ -255,18 +297,20 @@ extern "C" int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_
         if (lds > 64 * 1024) {                                                                                         \
             static bool attr_set = false;                                                                              \
             if (!attr_set) {                                                                                           \
-                MFSR_HIP_TRY(hipFuncSetAttribute((const void*)k_lkIterationFused<HT, TXV>,                             \
+                MFSR_HIP_TRY(hipFuncSetAttribute((const void*)k_lkIterationFused<HT, TXV, PRE>,                        \
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));             \
                 attr_set = true;                                                                                       \
             }                                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_lkIterationFused<HT, TXV>), grid, block, lds, mfsr_s(stream), (const float2*)shiftsIn,   \
+        hipLaunchKernelGGL((k_lkIterationFused<HT, TXV, PRE>), grid, block, lds, mfsr_s(stream), (const float2*)shiftsIn, \
                            (float2*)shiftsOut, pitchShift, refImg, movedImg, pitchImg, width, height, h, minDet,       \
-                           outScale);                                                                                 \
+                           outScale, sumIn, diffIn, sumOut, diffOut, pitchSD);                                         \
     } while (0)
 #define LK_CASE(HT)                                                                                                    \
     case HT:                                                                                                           \
-        if (TX == 48)                                                                                                  \
+        if (PRE && TX == 64)                                                                                           \
+            LK_LAUNCH(HT, 64);                                                                                         \
+        else if (TX == 48)                                                                                             \
             LK_LAUNCH(HT, 48);                                                                                         \
         else                                                                                                           \
             LK_LAUNCH(HT, 32);                                                                                         \
@@ -287,4 +331,91 @@ extern "C" int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_
 #undef LK_CASE
 #undef LK_LAUNCH
     return mfsr_launch_status("lucasKanadeIterationFused");
+}
+
+extern "C" int mfsr_lucasKanadeIterationFused(const mfsr_float2* shiftsIn, mfsr_float2* shiftsOut, int pitchShift,
+                                              const float* refImg, const float* movedImg, int pitchImg, int width,
+                                              int height, int halfWindowSize, float minDet, float outScale, mfsr_stream_t stream)
+{
+    return lk_iteration_impl<false>(shiftsIn, shiftsOut, pitchShift, refImg, movedImg, pitchImg, width, height, halfWindowSize, minDet,
+                                    outScale, nullptr, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mfsr_lucasKanadeIterationWarped(const mfsr_float2* shiftsIn, mfsr_float2* shiftsOut, int pitchShift,
+                                               const float* refImg, const float* movedImg, int pitchImg, const float* sumIn,
+                                               const float* diffIn, float* sumOut, float* diffOut, int pitchSD, int width, int height,
+                                               int halfWindowSize, float minDet, float outScale, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(sumIn && diffIn && (sumOut != nullptr) == (diffOut != nullptr) && sumOut != sumIn && diffOut != diffIn);
+    MFSR_REQUIRE((long long)pitchSD >= 4LL * width && (pitchSD & 3) == 0);
+    MFSR_REQUIRE(!sumOut || outScale == 1.0f);  // the flow a next iteration reads is in tracking pixels
+    return lk_iteration_impl<true>(shiftsIn, shiftsOut, pitchShift, refImg, movedImg, pitchImg, width, height, halfWindowSize, minDet,
+                                   outScale, sumIn, diffIn, sumOut, diffOut, pitchSD, stream);
+}
+
+// D1 (CreateFlowFieldFromTiles, opticalFlow.cu:48) + the warp of every pixel under that flow: the input of the first
+// mfsr_lucasKanadeIterationWarped.  Base shift / rotation by value (cosf / sinf on the device, as mfsr_CreateFlowFieldFromTiles)
+// or from a device mfsr_prealign (its cos / sin table, as mfsr_CreateFlowFieldFromTilesBase): the same flow bits either way.
+template <bool BASE_PTR>
+__global__ void __launch_bounds__(256)
+    k_flowFieldWarped(float2* __restrict__ outImg, mfsr_tex2d texShift, int imgWidth, int imgHeight, int imgPitch, float2 baseShift,
+                      float baseRotation, const mfsr_prealign* __restrict__ base, const float* __restrict__ refImg,
+                      const float* __restrict__ movedImg, int pitchImg, float* __restrict__ sumOut, float* __restrict__ diffOut,
+                      int pitchSD)
+{
+    const int pxX = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pxY = blockIdx.y * blockDim.y + threadIdx.y;
+    if (pxX >= imgWidth || pxY >= imgHeight) return;
+    float cf = 1.0f, sf = 0.0f, bx, by;
+    if (BASE_PTR) {
+        cf = base->cosRotation;
+        sf = base->sinRotation;
+        bx = base->shiftX;
+        by = base->shiftY;
+    } else {
+        // cosf(0) = 1 and sinf(0) = 0 exactly: the (uniform) zero-rotation case skips the two libm expansions
+        if (baseRotation != 0.0f) {
+            cf = cosf(baseRotation);
+            sf = sinf(baseRotation);
+        }
+        bx = baseShift.x;
+        by = baseShift.y;
+    }
+    float2 shift;
+    shift.x = cf * -bx - sf * -by;
+    shift.y = sf * -bx + cf * -by;
+    const float patchCenterX = (float)(pxX - imgWidth / 2);
+    const float patchCenterY = (float)(pxY - imgHeight / 2);
+    shift.x += cf * patchCenterX - sf * patchCenterY - patchCenterX;
+    shift.y += sf * patchCenterX + cf * patchCenterY - patchCenterY;
+    const float2 shiftPatch =
+        tex2<ADDR_CLAMP>(texShift, ((float)pxX + 0.5f) / (float)imgWidth, ((float)pxY + 0.5f) / (float)imgHeight);
+    shift.x += shiftPatch.x;
+    shift.y += shiftPatch.y;
+    row_ptr(outImg, imgPitch, pxY)[pxX] = shift;
+    float wv, rv;
+    lk_warp_sample(refImg, movedImg, pitchImg, imgWidth, imgHeight, pxX, pxY, shift, wv, rv);
+    row_ptr(sumOut, pitchSD, pxY)[pxX] = wv + rv;
+    row_ptr(diffOut, pitchSD, pxY)[pxX] = wv - rv;
+}
+
+extern "C" int mfsr_CreateFlowFieldWarped(mfsr_float2* outImg, mfsr_tex2d texObjShiftXY, int imgWidth, int imgHeight, int imgPitch,
+                                          mfsr_float2 baseShift, float baseRotation, const mfsr_prealign* base, const float* refImg,
+                                          const float* movedImg, int pitchImg, float* sumOut, float* diffOut, int pitchSD,
+                                          mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(outImg && refImg && movedImg && sumOut && diffOut && imgWidth > 0 && imgHeight > 0);
+    MFSR_REQUIRE((long long)imgPitch >= 8LL * imgWidth && (imgPitch & 7) == 0 && ((uintptr_t)outImg & 7) == 0);
+    MFSR_REQUIRE((long long)pitchImg >= 4LL * imgWidth && (pitchImg & 3) == 0 && (long long)pitchSD >= 4LL * imgWidth && (pitchSD & 3) == 0);
+    MFSR_REQUIRE(mfsr_tex_ok(texObjShiftXY, 8) && ((uintptr_t)texObjShiftXY.ptr & 7) == 0 && (texObjShiftXY.pitch & 7) == 0);
+    MFSR_REQUIRE(imgWidth >= 2 && imgHeight >= 2);
+    dim3 block(64, 4), grid(mfsr_cdiv(imgWidth, 64), mfsr_cdiv(imgHeight, 4));
+    if (base)
+        hipLaunchKernelGGL(k_flowFieldWarped<true>, grid, block, 0, mfsr_s(stream), (float2*)outImg, texObjShiftXY, imgWidth, imgHeight,
+                           imgPitch, make_float2(0.0f, 0.0f), 0.0f, base, refImg, movedImg, pitchImg, sumOut, diffOut, pitchSD);
+    else
+        hipLaunchKernelGGL(k_flowFieldWarped<false>, grid, block, 0, mfsr_s(stream), (float2*)outImg, texObjShiftXY, imgWidth, imgHeight,
+                           imgPitch, make_float2(baseShift.x, baseShift.y), baseRotation, base, refImg, movedImg, pitchImg, sumOut,
+                           diffOut, pitchSD);
+    return mfsr_launch_status("CreateFlowFieldWarped");
 }

@@ -67,6 +67,7 @@ struct Layout {
     Img shifts[kMaxLevels], pre[kMaxLevels]; // float2, tile grids
     // unfused path scratch
     Img warped, Ix, Iy, It, rawf;
+    Img lkSum[2], lkDiff[2];                 // fused LK: (warped + ref) / (warped - ref) handed from iteration to iteration
     float *refTiles, *movTiles, *cc, *boxX, *boxY, *sqsum, *dist;
     float* refSq[kMaxLevels];  // fused tracker: sum(ref^2) per tile and level, taken once per reference
     // global pre-alignment (cfg.preAlign): search pyramids of the reference and the moved frame, workspace, result
@@ -187,8 +188,13 @@ void make_layout(const mfsr_config* c, char* base, Layout* L)
         if (tiles * R * R > maxDist) maxDist = tiles * R * R;
     }
     for (int l = 0; l < kMaxLevels; l++) L->refSq[l] = nullptr;
-    if (c->fused)
+    if (c->fused) {
         for (int l = 0; l < c->levels; l++) L->refSq[l] = (float*)b.take((size_t)L->tcx[l] * L->tcy[l] * 4);
+        for (int i = 0; i < 2; i++) {
+            L->lkSum[i] = b.image(L->tw, L->th, 4);
+            L->lkDiff[i] = b.image(L->tw, L->th, 4);
+        }
+    }
     if (!c->fused) {
         L->warped = b.image(L->tw, L->th, 4);
         L->Ix = b.image(L->tw, L->th, 4);
@@ -797,7 +803,19 @@ static int align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, int 
         const int last = c.levels - 1;
         const Img& tileShifts = b->givenShifts ? *b->givenShifts : L.shifts[last];
         const mfsr_float2 zero2 = {0.0f, 0.0f};
-        if (c.preAlign && c.fused) {
+        // fused LK: the warped moved image travels from launch to launch (every pixel warped once per iteration, by the
+        // thread that has just updated its flow) instead of being re-gathered for every tile halo; MFSR_LK_WARPED=0: A/B
+        static const bool lkWarped = [] {
+            const char* e = getenv("MFSR_LK_WARPED");
+            return !(e && e[0] == '0');
+        }();
+        const bool warped = c.fused && lkWarped && c.lkIterations > 0 && L.tw >= 64 && L.th >= 32;
+        if (warped) {
+            TRY(mfsr_CreateFlowFieldWarped((mfsr_float2*)flow->ptr, as_tex(tileShifts), L.tw, L.th, flow->pitch, zero2, 0.0f,
+                                           c.preAlign ? L.preResult : nullptr, (const float*)L.refPyr[0].ptr,
+                                           (const float*)L.movPyr[0].ptr, L.refPyr[0].pitch, (float*)L.lkSum[0].ptr,
+                                           (float*)L.lkDiff[0].ptr, L.lkSum[0].pitch, stream));
+        } else if (c.preAlign && c.fused) {
             TRY(mfsr_CreateFlowFieldFromTilesBase((mfsr_float2*)flow->ptr, as_tex(tileShifts), L.tw, L.th, flow->pitch,
                                                   L.preResult, stream));
         } else {
@@ -812,7 +830,19 @@ static int align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, int 
                                               L.tcy[last], L.tw, L.th, flow->pitch, base, rot, stream));
         }
         for (int it = 0; it < c.lkIterations; it++) {
-            if (c.fused) {
+            if (warped) {
+                const bool lastIt = it == c.lkIterations - 1;
+                const int in = it & 1, out = in ^ 1;
+                TRY(mfsr_lucasKanadeIterationWarped((const mfsr_float2*)flow->ptr, (mfsr_float2*)other->ptr, flow->pitch,
+                                                    (const float*)L.refPyr[0].ptr, (const float*)L.movPyr[0].ptr, L.refPyr[0].pitch,
+                                                    (const float*)L.lkSum[in].ptr, (const float*)L.lkDiff[in].ptr,
+                                                    lastIt ? nullptr : (float*)L.lkSum[out].ptr,
+                                                    lastIt ? nullptr : (float*)L.lkDiff[out].ptr, L.lkSum[0].pitch, L.tw, L.th,
+                                                    c.lkHalfWindow, c.lkMinDet, lastIt ? (float)L.flowScale : 1.0f, stream));
+                Img* t = flow;
+                flow = other;
+                other = t;
+            } else if (c.fused) {
                 TRY(mfsr_lucasKanadeIterationFused((const mfsr_float2*)flow->ptr, (mfsr_float2*)other->ptr, flow->pitch,
                                                    (const float*)L.refPyr[0].ptr, (const float*)L.movPyr[0].ptr,
                                                    L.refPyr[0].pitch, L.tw, L.th, c.lkHalfWindow, c.lkMinDet,

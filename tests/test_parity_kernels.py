@@ -961,6 +961,46 @@ def test_lucasKanadeIterationFused_equals_chain(orc, hip, hw):
         assert err1 < err0
 
 
+@pytest.mark.parametrize("hw,W,H", [(3, 100, 70), (3, 333, 141), (2, 64, 40), (5, 130, 90)])
+def test_lucasKanadeIterationWarped_is_bit_identical(hip, hw, W, H):
+    """mfsr_CreateFlowFieldWarped + three mfsr_lucasKanadeIterationWarped (the warped image handed from launch to launch,
+    every pixel warped once per iteration) == mfsr_CreateFlowFieldFromTiles + three mfsr_lucasKanadeIterationFused (tile +
+    halo re-warped by every workgroup): same flow, bit for bit, ragged tiles and mirrored halos included; also with the
+    base shift / rotation read from a device mfsr_prealign."""
+    r = rng(333)
+    base = _smooth_image(58, H + 8, W + 8)
+    ref = np.ascontiguousarray(base[4:4 + H, 4:4 + W])
+    mov = np.ascontiguousarray(base[3:3 + H, 6:6 + W])
+    tcx, tcy = 5, 4
+    tiles = r.uniform(-2.5, 2.5, (tcy, tcx, 2)).astype(np.float32)
+    z = F2([0, 0])
+    for use_base in (False, True):
+        pa = np.zeros(12, np.float32)   # mfsr_prealign: shiftX, shiftY, rotation, cos, sin, 7 x int32
+        ang = np.float32(0.02)
+        pa[:5] = [1.5, -0.75, ang, np.cos(ang, dtype=np.float32), np.sin(ang, dtype=np.float32)]
+        flows = [np.zeros((H, W, 2), np.float32) for _ in range(2)]
+        if use_base:
+            hip.call("CreateFlowFieldFromTilesBase", flows[0], Tex(tiles), W, H, pitch_of(flows[0]), pa)
+        else:
+            hip.call("CreateFlowFieldFromTiles", flows[0], Tex(tiles), 16, tcx, tcy, W, H, pitch_of(flows[0]), z, 0.0)
+        for it in range(3):
+            hip.call("lucasKanadeIterationFused", flows[it & 1], flows[(it & 1) ^ 1], pitch_of(flows[0]), ref, mov, pitch_of(ref),
+                     W, H, hw, 1e-4, 2.0 if it == 2 else 1.0)
+        want = flows[1]
+        f = [np.zeros((H, W, 2), np.float32) for _ in range(2)]
+        S = [np.full((H, W), np.nan, np.float32) for _ in range(2)]
+        D = [np.full((H, W), np.nan, np.float32) for _ in range(2)]
+        hip.call("CreateFlowFieldWarped", f[0], Tex(tiles), W, H, pitch_of(f[0]), z, 0.0, pa if use_base else None, ref, mov,
+                 pitch_of(ref), S[0], D[0], pitch_of(S[0]))
+        for it in range(3):
+            i, o = it & 1, (it & 1) ^ 1
+            last = it == 2
+            hip.call("lucasKanadeIterationWarped", f[i], f[o], pitch_of(f[0]), ref, mov, pitch_of(ref), S[i], D[i],
+                     None if last else S[o], None if last else D[o], pitch_of(S[0]), W, H, hw, 1e-4, 2.0 if last else 1.0)
+        assert_bitexact(want, f[1], f"warped LK chain (base={use_base})")
+        assert np.abs(want).max() > 0.5
+
+
 def test_structure_tensor_and_kernel_param(orc, hip):
     H, W = 44, 60
     img = _smooth_image(57, H, W)
