@@ -335,11 +335,15 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
 // waves (a wave with one border strip used to execute both paths: +12 % VALU instructions).
 #define STRIP_MARGIN 16
 
+// SCALE is a template parameter: the straight arithmetic takes floor((x + px + sx) / scale) twenty times per pixel, and an
+// integer division by a run-time value is ~40 instructions -- half of this kernel's work when the scale was a kernel argument
+template <int SCALE>
 __global__ void __launch_bounds__(256)
     k_accumulateMargin(const uint16_t* __restrict__ raw, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights,
                        const float4* __restrict__ certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts, Levels3 glv,
-                       int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int scale, int rowBegin, int rowEnd)
+                       int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int rowBegin, int rowEnd)
 {
+    constexpr int scale = SCALE;
     const int hrW = scale * dimX, hrH = scale * dimY, M = STRIP_MARGIN;
     const int rowLen = hrW - 2;                    // x in [1, hrW-1)
     const int nTop = (M - 1) * rowLen;             // y in [1, M)
@@ -385,12 +389,12 @@ struct TileFrames {
 // parameters, then raw and certainty per tap) on 7.6 K wavefronts at 4K: one thread per (pixel, frame) -- 64 pixels x NF
 // frames per workgroup -- keeps the chain one frame long; the frames' sums (each taken from zero) meet in LDS and are
 // added to the accumulators in call order by the pixel's first thread, which reads and writes them once.
-template <int NF>
+template <int NF, int SCALE>
 __global__ void __launch_bounds__(64 * NF)
     k_accumulateMarginN(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
-                        Levels3 glv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int scale, int rowBegin,
-                        int rowEnd)
+                        Levels3 glv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int rowBegin, int rowEnd)
 {
+    constexpr int scale = SCALE;
     __shared__ float sSum[NF][6][64];
     const int hrW = scale * dimX, hrH = scale * dimY, M = STRIP_MARGIN;
     const int rowLen = hrW - 2;
@@ -1500,8 +1504,8 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
     auto launch_margin = [&](int n) {
         const int M = STRIP_MARGIN;
         const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
-        hipLaunchKernelGGL(k_accumulateMargin, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, mst, dataIn[n], pI, pT,
-                           (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp, 2,
+        hipLaunchKernelGGL(k_accumulateMargin<2>, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, mst, dataIn[n], pI, pT,
+                           (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp,
                            rowBegin, rowEnd);
         if (msx && n == nFrames - 1) {
             (void)hipEventRecord(msx->join, msx->stream);
@@ -1521,8 +1525,8 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
                              rowBlock0);
         const int M = STRIP_MARGIN;
         const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
-        hipLaunchKernelGGL(k_accumulateMarginN<NF>, dim3(mfsr_cdiv(cnt, 64)), dim3(64, NF), 0, mst, fr, pI, pT, kernelParam, glv, dimX,
-                           dimY, strideOut, strideMask, cp, 2, rowBegin, rowEnd);
+        hipLaunchKernelGGL((k_accumulateMarginN<NF, 2>), dim3(mfsr_cdiv(cnt, 64)), dim3(64, NF), 0, mst, fr, pI, pT, kernelParam, glv,
+                           dimX, dimY, strideOut, strideMask, cp, rowBegin, rowEnd);
         if (msx) {
             (void)hipEventRecord(msx->join, msx->stream);
             (void)hipStreamWaitEvent(st, msx->join, 0);
@@ -1620,8 +1624,8 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
     auto launch_margin = [&](int n) {
         const int M = STRIP_MARGIN;
         const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
-        hipLaunchKernelGGL(k_accumulateMargin, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, mst, dataIn[n], pI, pT,
-                           (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp, 4,
+        hipLaunchKernelGGL(k_accumulateMargin<4>, dim3(mfsr_cdiv(cnt, 256)), dim3(256), 0, mst, dataIn[n], pI, pT,
+                           (const float4*)certaintyMask[n], kernelParam, shifts[n], glv, dimX, dimY, strideOut, strideMask, cp,
                            rowBegin, rowEnd);
         if (msx && n == nFrames - 1) {
             (void)hipEventRecord(msx->join, msx->stream);
