@@ -334,6 +334,12 @@ __device__ __forceinline__ void strip_pixel(int X, int Y, int sx, int sy, float 
 // Handling them in a separate small launch keeps the fast kernels free of divergent border
 // waves (a wave with one border strip used to execute both paths: +12 % VALU instructions).
 #define STRIP_MARGIN 16
+// margin kernels: branch-free taps with per-colour sums (tap_accumulate_sums: 81 -> 55 us per 4-frame margin launch at
+// 4K); 0: colour branches (A/B).  (The tile kernels' in-kernel straight path keeps the branches: the unrolled branch-free
+// taps push those kernels over their register budget.)
+#ifndef MARGIN_TAP_SUMS
+#define MARGIN_TAP_SUMS 1
+#endif
 
 // SCALE is a template parameter: the straight arithmetic takes floor((x + px + sx) / scale) twenty times per pixel, and an
 // integer division by a run-time value is ~40 instructions -- half of this kernel's work when the scale was a kernel argument
@@ -368,7 +374,7 @@ __global__ void __launch_bounds__(256)
         return;
     }
     if (y < rowBegin || y >= rowEnd) return;  // HR row window of this launch (stripe-sharded bursts)
-    accumulate_pixel_generic<GEOM_FULL, true>(x, y, raw, imgOut, totalWeights, certaintyMask, kernelParam, shifts, glv, dimX,
+    accumulate_pixel_generic<GEOM_FULL, true, MARGIN_TAP_SUMS>(x, y, raw, imgOut, totalWeights, certaintyMask, kernelParam, shifts, glv, dimX,
                                               dimY, scale, strideOut, strideMask, cfaPacked);
 }
 
@@ -424,8 +430,8 @@ __global__ void __launch_bounds__(64 * NF)
 #pragma unroll
         for (int m = 1; m < NF; m++)
             if (n == m) F = fr.f[m];
-        accumulate_pixel_core<GEOM_FULL, true>(x, y, F.raw, F.mask, kernelParam, F.shifts, glv, dimX, dimY, scale, strideMask, cfaPacked,
-                                               pixel, totalWeight);
+        accumulate_pixel_core<GEOM_FULL, true, MARGIN_TAP_SUMS>(x, y, F.raw, F.mask, kernelParam, F.shifts, glv, dimX, dimY, scale,
+                                                                strideMask, cfaPacked, pixel, totalWeight);
     }
     sSum[n][0][lane] = pixel.x;
     sSum[n][1][lane] = pixel.y;
