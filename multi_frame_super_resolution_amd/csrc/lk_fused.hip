@@ -95,10 +95,14 @@ __global__ void __launch_bounds__(LK_TX * LK_TY)
     extern __shared__ __attribute__((aligned(16))) float s_lk[];
     const int BW = LK_TX + 2 * h + 4, BH = LK_TY + 2 * h + 4;  // warped / ref region
     const int AW = LK_TX + 2 * h, AH = LK_TY + 2 * h;          // derivative region
+    // row stride of the product planes: a multiple of 4 floats when h is a compile-time constant, so that the row pass
+    // reads its window with aligned ds_read_b128 (lanes 16 bytes apart: conflict-free) instead of dwords 16 bytes apart
+    // (4-way bank conflicts)
+    const int AWp = HT > 0 ? ((AW + 3) & ~3) : AW;
     float* s_ref = s_lk;
     float* s_wrp = s_ref + BW * BH;
-    float* s_p = s_wrp + BW * BH;      // 5 planes of AW*AH
-    float* s_h = s_p + 5 * AW * AH;    // 5 planes of LK_TX*AH
+    float* s_p = s_wrp + BW * BH;      // 5 planes of AWp*AH
+    float* s_h = s_p + 5 * AWp * AH;   // 5 planes of LK_TX*AH
     const int x0 = blockIdx.x * LK_TX, y0 = blockIdx.y * LK_TY;
     const int tid = threadIdx.y * LK_TX + threadIdx.x;
 
@@ -139,9 +143,10 @@ __global__ void __launch_bounds__(LK_TX * LK_TY)
     __syncthreads();
 
     // 2. derivatives and products on the tile + h halo
-    const int planeA = AW * AH;
-    for (int i = tid; i < planeA; i += LK_THREADS) {
-        const int ay = i / AW, ax = i - ay * AW;
+    const int planeA = AWp * AH;
+    for (int i0 = tid; i0 < AW * AH; i0 += LK_THREADS) {
+        const int ay = i0 / AW, ax = i0 - ay * AW;
+        const int i = ay * AWp + ax;
         const float* r = s_ref + (ay + 2) * BW + (ax + 2);  // warped + ref
         // opticalFlow.cu:116-131 with source = warped, target = reference (see header note):
         // Ix = (d(warped) + d(ref)) / 2 with d = (f[2] - 8 f[1] + 8 f[-1] - f[-2]) / 12, taken on the sum image
@@ -174,10 +179,14 @@ __global__ void __launch_bounds__(LK_TX * LK_TY)
             const int k = i / (AH * G);
             const int r = i - k * (AH * G);
             const int ay = r / G, x = (r - ay * G) * 4;
-            const float* p = s_p + k * planeA + ay * AW + x;
-            float v[WIN + 3];
+            const float4* p4 = (const float4*)(s_p + k * planeA + ay * AWp + x);  // 16-byte aligned: AWp, planeA, x % 4 == 0
+            constexpr int NV = (WIN + 3 + 3) / 4;
+            float v[4 * NV];
 #pragma unroll
-            for (int d = 0; d < WIN + 3; d++) v[d] = p[d];
+            for (int d = 0; d < NV; d++) {
+                const float4 t = p4[d];
+                v[4 * d] = t.x, v[4 * d + 1] = t.y, v[4 * d + 2] = t.z, v[4 * d + 3] = t.w;
+            }
             float o[4];
             if (WIN >= 4) {
                 float core = v[3];
@@ -206,7 +215,7 @@ __global__ void __launch_bounds__(LK_TX * LK_TY)
             const int k = i / planeH;
             const int r = i - k * planeH;
             const int ay = r / LK_TX, x = r - ay * LK_TX;
-            const float* p = s_p + k * planeA + ay * AW + x;
+            const float* p = s_p + k * planeA + ay * AWp + x;
             float s = 0;
             for (int d = 0; d < win; d++) s += p[d];
             s_h[i] = s;
@@ -288,7 +297,8 @@ static int lk_iteration_impl(const mfsr_float2* shiftsIn, mfsr_float2* shiftsOut
     if (forceTx == 48 && hasWide && width >= 48 + 2 * h + 4) TX = 48;
     if (PRE && forceTx == 64 && hasWide && width >= 64 + 2 * h + 4) TX = 64;
     const int BW = TX + 2 * h + 4, BH = LK_TY + 2 * h + 4, AW = TX + 2 * h, AH = LK_TY + 2 * h;
-    const size_t lds = sizeof(float) * ((size_t)2 * BW * BH + (size_t)5 * AW * AH + (size_t)5 * TX * AH);
+    const int AWp = hasWide ? ((AW + 3) & ~3) : AW;  // as in the kernel: padded when h is a template parameter
+    const size_t lds = sizeof(float) * ((size_t)2 * BW * BH + (size_t)5 * AWp * AH + (size_t)5 * TX * AH);
     if (lds > 160 * 1024) return MFSR_E_UNSUPPORTED;
     MFSR_REQUIRE(width >= TX + 2 * h + 4 && height >= LK_TY + 2 * h + 4);  // reflection range of the halo
     dim3 block(TX, LK_TY), grid(mfsr_cdiv(width, TX), mfsr_cdiv(height, LK_TY));
