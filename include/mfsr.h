@@ -121,8 +121,8 @@ int mfsr_accumulateSuperResFull2(const uint16_t* dataIn0, const uint16_t* dataIn
                                  int scale, int strideOut, int strideMask, mfsr_stream_t stream);
 
 /* nFrames (1 .. MFSR_MAX_FUSE_GROUP) frames in one call (dataIn / certaintyMask / shifts: host arrays of nFrames entries);
- * the frames add in call order.  At scale 2 with the fields at a quarter of the HR size (the Bayer pipeline) the whole group
- * is ONE pass over the accumulators; other geometries take it two frames at a time.
+ * the frames add in call order.  At scale 2 / 4 with the fields at a quarter / an eighth of the HR size (the Bayer pipeline)
+ * the whole group is ONE pass over the accumulators; other geometries take it two frames at a time.
  * accumulatorsUndefined != 0: imgOut / totalWeights are OVERWRITTEN as if they had been zeroed before
  * the call -- the first launch of a burst needs neither the memset nor the read of the two planes. */
 int mfsr_accumulateSuperResFullN(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
@@ -434,7 +434,7 @@ typedef struct {
     int32_t applyGamma;
     int32_t fused;           /* 1: fused MI355X kernels; 0: one launch per reference kernel */
     int32_t pairFrames;      /* frames per warp+fuse launch of add_frame (see mfsr_burst_add_frame): 0 = one, like the
-                                reference; 1 (default) = as many as one launch takes (MFSR_MAX_FUSE_GROUP at scale 2, else 2);
+                                reference; 1 (default) = as many as one launch takes (MFSR_MAX_FUSE_GROUP at scale 2 and 4 Bayer, else 2);
                                 2 .. MFSR_MAX_FUSE_GROUP = that many */
     int32_t asyncFuse;       /* 1 (default): the warp+fuse launches run on a stream owned by the burst, concurrently with the
                                 alignment of the following frames on the caller's stream (see mfsr_burst_add_frame) */

@@ -250,6 +250,13 @@ extern "C" int mfsr_accumulateSuperResFullRows(int nFrames, const uint16_t* cons
         if (r == 1) return mfsr_launch_status("accumulateSuperResFullN(strip)");
         if (r < 0) return MFSR_E_INVALID;
     }
+    if (g_accumulate_fast == 2 && scale == 4) {
+        const int r = mfsr_try_launch_accumulate4x_tile(nFrames, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts,
+                                                        whiteLevel, blackLevel, dimX, dimY, strideOut, strideMask, fresh, rowBegin,
+                                                        rowEnd, stream);
+        if (r == 1) return mfsr_launch_status("accumulateSuperResFullN(x4 tile)");
+        if (r < 0) return MFSR_E_INVALID;
+    }
     if (nFrames > 2) {
         // no kernel of this geometry takes the whole group: two frames, then the rest
         const int rc = mfsr_accumulateSuperResFullRows(2, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, whiteLevel,
@@ -259,13 +266,6 @@ extern "C" int mfsr_accumulateSuperResFullRows(int nFrames, const uint16_t* cons
         return mfsr_accumulateSuperResFullRows(nFrames - 2, dataIn + 2, imgOut, totalWeights, certaintyMask + 2, kernelParam,
                                                shifts + 2, whiteLevel, blackLevel, dimX, dimY, scale, strideOut, strideMask, 0,
                                                rowBegin, rowEnd, stream);
-    }
-    if (g_accumulate_fast == 2 && scale == 4) {
-        const int r = mfsr_try_launch_accumulate4x_tile(nFrames, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts,
-                                                        whiteLevel, blackLevel, dimX, dimY, strideOut, strideMask, fresh, rowBegin,
-                                                        rowEnd, stream);
-        if (r == 1) return mfsr_launch_status("accumulateSuperResFullN(x4 tile)");
-        if (r < 0) return MFSR_E_INVALID;
     }
     if (fresh) {
         const size_t off = (size_t)rowBegin * strideOut, bytes = (size_t)(rowEnd - rowBegin) * strideOut;

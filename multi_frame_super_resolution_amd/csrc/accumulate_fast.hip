@@ -1022,10 +1022,10 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
 // mask per tap column (none for it = 0, all for it = 4), applied to the weights as in strip_pixel.
 // Each site is its own CFA-position class (relative to the parity of (x0, y0)).  K8 = X & 7 is the
 // pixel's position in its certainty cell (8 HR pixels at scale 4), K8 & 3 its position in the strip.
-template <int K8, int CFA, bool PARITY = false, typename MaskF>
-__device__ __forceinline__ void strip_pixel4(int X, int Y, int sx, int sy, float kx, float ky, float kz,
-                                              const uint16_t* __restrict__ raw, int dimX, MaskF mval,
-                                              const StripLevels& lv, float* accP, float* accW)
+// strip_pixel4_w: the tap weights given (frame independent, see strip_pixel_w); RawF: void rawf(x0, y0, float (&s)[2][2])
+template <int K8, int CFA, bool PARITY = false, typename RawF, typename MaskF>
+__device__ __forceinline__ void strip_pixel4_w(int X, int Y, int sx, int sy, const float (&w)[13], RawF rawf, MaskF mval,
+                                                const StripLevels& lv, float* accP, float* accW)
 {
     const int qx = X + sx - 2, qy = Y + sy - 2;
     const int x0 = qx >> 2, y0 = qy >> 2;
@@ -1038,15 +1038,7 @@ __device__ __forceinline__ void strip_pixel4(int X, int Y, int sx, int sy, float
     auto andm = [](uint32_t m, float a) { return __uint_as_float(m & __float_as_uint(a)); };
 
     float s[2][2];
-    {
-        const uint16_t* r = raw + (size_t)y0 * dimX + x0;
-        s[0][0] = (float)r[0];
-        s[0][1] = (float)r[1];
-        s[1][0] = (float)r[dimX];
-        s[1][1] = (float)r[dimX + 1];
-    }
-    float w[13];
-    tap_weights13(kx, ky, kz, w);
+    rawf(x0, y0, s);
     auto W_ = [&](int jt, int it) { const int n = jt * 5 + it; return w[n <= 12 ? n : 24 - n]; };
 
     // certainty cell column of tap column it, relative to the cell left of the strip's own: 0..2
@@ -1115,6 +1107,23 @@ __device__ __forceinline__ void strip_pixel4(int X, int Y, int sx, int sy, float
         S[1][i] = s[1][i] * o1;
     }
     classes_to_channels<(K8 & 3), CFA>(S, W, mP, mQ, lv, accP, accW);
+}
+
+template <int K8, int CFA, bool PARITY = false, typename MaskF>
+__device__ __forceinline__ void strip_pixel4(int X, int Y, int sx, int sy, float kx, float ky, float kz,
+                                              const uint16_t* __restrict__ raw, int dimX, MaskF mval,
+                                              const StripLevels& lv, float* accP, float* accW)
+{
+    float w[13];
+    tap_weights13(kx, ky, kz, w);
+    auto rawf = [&](int x0, int y0, float (&s)[2][2]) {
+        const uint16_t* r = raw + (size_t)y0 * dimX + x0;
+        s[0][0] = (float)r[0];
+        s[0][1] = (float)r[1];
+        s[1][0] = (float)r[dimX];
+        s[1][1] = (float)r[dimX + 1];
+    };
+    strip_pixel4_w<K8, CFA, PARITY>(X, Y, sx, sy, w, rawf, mval, lv, accP, accW);
 }
 
 // x4 LDS tile kernel (fields at HR/8: the Bayer pipeline at scale 4).  One 64x4 workgroup covers a
@@ -1252,6 +1261,76 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : TILE4_WAVES2)
     const uint32_t xmax = (uint32_t)(4 * dimX - 5), ymax = (uint32_t)(4 * dimY - 5);
     const int yq = Y & 7;
     uint32_t safeBits = 0;
+    static_assert(NF <= 2 || TILE_PIXEL_MAJOR, "three and four frames per launch exist in pixel-major order only");
+#if TILE_PIXEL_MAJOR
+    if constexpr (NF > 1) {
+        // pixel-major, as k_accumulate2xTile: per frame the whole-pixel flow of the strip's pixels and the admission, then
+        // per pixel the tap weights once and frame after frame
+        uint32_t sxy[NF][4];
+#pragma unroll
+        for (int n = 0; n < NF; n++) {
+            float2 Ft[2][2];
+#pragma unroll
+            for (int r2 = 0; r2 < 2; r2++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) Ft[r2][c] = sF[n][fr_ + r2][cb + c];
+            bool safe = geomOk && kOk;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float ux = lerp4(Ft[0][0].x, Ft[0][1].x, Ft[1][0].x, Ft[1][1].x, av[k], b);
+                const float uy = lerp4(Ft[0][0].y, Ft[0][1].y, Ft[1][0].y, Ft[1][1].y, av[k], b);
+                const int sx = round2i(ux * 4.0f), sy = round2i(uy * 4.0f);
+                const int qx = X0 + k + sx - 2, qy = Y + sy - 2;
+                safe = safe && (uint32_t)(sx + (1 << 15)) < (2u << 15) && (uint32_t)(sy + (1 << 15)) < (2u << 15) &&
+                       (uint32_t)qx <= xmax && (uint32_t)qy <= ymax;
+                sxy[n][k] = ((uint32_t)sx & 0xffffu) | ((uint32_t)sy << 16);
+            }
+            if (safe) safeBits |= 1u << n;
+        }
+        const float* mrow[5];
+#pragma unroll
+        for (int jt = 0; jt < 5; jt++) mrow[jt] = (const float*)&sM[0][(yq + jt - 2 + 8) >> 3][lx];
+        const char* rawRow[NF][2];
+#pragma unroll
+        for (int n = 0; n < NF; n++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) rawRow[n][j] = (const char*)(fr.f[n].raw + (size_t)j * dimX);
+        auto pixel = [&](auto k8c) {
+            constexpr int K8 = decltype(k8c)::value, k = K8 & 3;
+            if (safeBits == 0) return;
+            float w[13];
+            tap_weights13(kxa[k], kya[k], kza[k], w);
+#pragma unroll
+            for (int n = 0; n < NF; n++) {
+                if ((safeBits >> n) & 1u) {
+                    auto rawf = [&](int x0, int y0, float (&sv)[2][2]) {
+                        const uint32_t boff = (uint32_t)(y0 * dimX + x0) * 2u;  // admitted strips: inside the frame
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            const char* rb = rawRow[n][j] + (size_t)boff;
+                            sv[j][0] = (float)*(const uint16_t*)rb;
+                            sv[j][1] = (float)*(const uint16_t*)(rb + 2);
+                        }
+                    };
+                    auto mval = [&](int jt, int cell, int e) { return mrow[jt][n * (3 * TILE_COLS * 4) + cell * 4 + e]; };
+                    const int sx = (int)(int16_t)(sxy[n][k] & 0xffffu), sy = (int)sxy[n][k] >> 16;
+                    strip_pixel4_w<K8, CFA, true>(X0 + k, Y, sx, sy, w, rawf, mval, lv, accP, accW);
+                }
+            }
+        };
+        if (h == 0) {
+            pixel(std::integral_constant<int, 0>{});
+            pixel(std::integral_constant<int, 1>{});
+            pixel(std::integral_constant<int, 2>{});
+            pixel(std::integral_constant<int, 3>{});
+        } else {
+            pixel(std::integral_constant<int, 4>{});
+            pixel(std::integral_constant<int, 5>{});
+            pixel(std::integral_constant<int, 6>{});
+            pixel(std::integral_constant<int, 7>{});
+        }
+    } else
+#endif
 #pragma unroll 1
     for (int n = 0; n < NF; n++) {
         const uint16_t* raw = (NF > 1 && n) ? fr.f[NF - 1].raw : fr.f[0].raw;
@@ -1317,7 +1396,10 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : TILE4_WAVES2)
     }
 #pragma unroll 1
     for (int n = 0; n < NF; n++) {
-        const TileFrame& F = (NF > 1 && n) ? fr.f[NF - 1] : fr.f[0];
+        TileFrame F = fr.f[0];  // picked with scalar selects: the argument struct stays in SGPRs
+#pragma unroll
+        for (int m = 1; m < NF; m++)
+            if (n == m) F = fr.f[m];
         if (!((safeBits >> n) & 1u) && stripLive) {
 #pragma unroll 1
             for (int k = 0; k < 4; k++) {
@@ -1582,7 +1664,7 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
     return 0;
 }
 
-// x4: returns 1 if the x4 tile kernel took the nFrames (1 or 2) frames, 0 if the geometry is not its
+// x4: returns 1 if the x4 tile kernel took the nFrames (1 to 4) frames, 0 if the geometry is not its
 // (fields at HR/8, even dimensions); the caller then uses the straight kernel.
 int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
                                       mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
@@ -1591,7 +1673,7 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
                                       int fresh, int rowBegin, int rowEnd, mfsr_stream_t stream)
 {
     read_env_once();
-    if (nFrames < 1 || nFrames > 2 || !g_strip_use_tile) return 0;
+    if (nFrames < 1 || nFrames > 4 || !g_strip_use_tile) return 0;
     int cfa[4];
     mfsr_get_cfa_pattern(cfa);
     for (int i = 0; i < 4; i++)
@@ -1638,29 +1720,39 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
             (void)hipStreamWaitEvent(st, msx->join, 0);
         }
     };
+    // NF frames: the tile kernel, then their margin pixels in one launch (one frame: the single-frame margin kernel)
+    auto launch_group = [&](auto cfaTag, auto nfTag) {
+        constexpr int CFA = decltype(cfaTag)::value, NF = decltype(nfTag)::value;
+        TileFrames<NF> fr;
+        for (int n = 0; n < NF; n++) {
+            fr.f[n].raw = dataIn[n];
+            fr.f[n].mask = (const float4*)certaintyMask[n];
+            fr.f[n].shifts = shifts[n];
+        }
+        hipLaunchKernelGGL((k_accumulate4xTile<CFA, NF>), grid, block, 0, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY, strideOut,
+                           strideMask, cp, tilesX, fresh ? 1 : 0, tileY0);
+        if (NF == 1) {
+            launch_margin(0);
+            return;
+        }
+        const int M = STRIP_MARGIN;
+        const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
+        hipLaunchKernelGGL((k_accumulateMarginN<NF, 4>), dim3(mfsr_cdiv(cnt, 64)), dim3(64, NF), 0, mst, fr, pI, pT, kernelParam, glv,
+                           dimX, dimY, strideOut, strideMask, cp, rowBegin, rowEnd);
+        if (msx) {
+            (void)hipEventRecord(msx->join, msx->stream);
+            (void)hipStreamWaitEvent(st, msx->join, 0);
+        }
+    };
 #define X4_CASE(a, b, c, d)                                                                                            \
-    case pack_cfa(a, b, c, d):                                                                                         \
-        if (nFrames == 2) {                                                                                            \
-            TileFrames<2> fr;                                                                                          \
-            for (int n = 0; n < 2; n++) {                                                                              \
-                fr.f[n].raw = dataIn[n];                                                                               \
-                fr.f[n].mask = (const float4*)certaintyMask[n];                                                        \
-                fr.f[n].shifts = shifts[n];                                                                            \
-            }                                                                                                          \
-            hipLaunchKernelGGL((k_accumulate4xTile<pack_cfa(a, b, c, d), 2>), grid, block, 0, st, fr, pI, pT, kernelParam, \
-                               glv, lv, dimX, dimY, strideOut, strideMask, cp, tilesX, fresh ? 1 : 0, tileY0);                 \
-            launch_margin(0);                                                                                          \
-            launch_margin(1);                                                                                          \
-        } else {                                                                                                       \
-            TileFrames<1> fr;                                                                                          \
-            fr.f[0].raw = dataIn[0];                                                                                   \
-            fr.f[0].mask = (const float4*)certaintyMask[0];                                                            \
-            fr.f[0].shifts = shifts[0];                                                                                \
-            hipLaunchKernelGGL((k_accumulate4xTile<pack_cfa(a, b, c, d), 1>), grid, block, 0, st, fr, pI, pT, kernelParam, \
-                               glv, lv, dimX, dimY, strideOut, strideMask, cp, tilesX, fresh ? 1 : 0, tileY0);                 \
-            launch_margin(0);                                                                                          \
-        }                                                                                                              \
-        return 1;
+    case pack_cfa(a, b, c, d): {                                                                                       \
+        using CfaTag = std::integral_constant<int, pack_cfa(a, b, c, d)>;                                              \
+        if (nFrames == 1) launch_group(CfaTag{}, std::integral_constant<int, 1>{});                                    \
+        if (nFrames == 2) launch_group(CfaTag{}, std::integral_constant<int, 2>{});                                    \
+        if (nFrames == 3) launch_group(CfaTag{}, std::integral_constant<int, 3>{});                                    \
+        if (nFrames == 4) launch_group(CfaTag{}, std::integral_constant<int, 4>{});                                    \
+        return 1;                                                                                                      \
+    }
     switch (packed2) {
         X4_CASE(MFSR_RED, MFSR_GREEN, MFSR_GREEN, MFSR_BLUE)   // RGGB
         X4_CASE(MFSR_BLUE, MFSR_GREEN, MFSR_GREEN, MFSR_RED)   // BGGR

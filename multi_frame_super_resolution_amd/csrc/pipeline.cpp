@@ -912,8 +912,8 @@ extern "C" int mfsr_burst_group_size(const mfsr_config* cfg)
 {
     if (!cfg || cfg->pairFrames <= 0) return 1;
     if (cfg->pairFrames >= 2) return cfg->pairFrames < MFSR_MAX_FUSE_GROUP ? cfg->pairFrames : MFSR_MAX_FUSE_GROUP;
-    // as many as one launch takes: the x2 Bayer tile kernel fuses four, every other geometry two
-    return (cfg->scale == 2 && !cfg->mono) ? MFSR_MAX_FUSE_GROUP : 2;
+    // as many as one launch takes: the x2 and x4 Bayer tile kernels fuse four, every other geometry two
+    return ((cfg->scale == 2 || cfg->scale == 4) && !cfg->mono) ? MFSR_MAX_FUSE_GROUP : 2;
 }
 
 // ---- building blocks of stripe-sharded bursts (multi-GPU: frames are aligned where they live, every rank fuses ALL
