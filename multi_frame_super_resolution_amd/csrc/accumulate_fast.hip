@@ -656,8 +656,10 @@ __global__ void __launch_bounds__(256)
 // both: the accumulator staging and write-back (the 48 B/px/frame of HBM traffic become 24), the
 // kernel-parameter mix, the column/row fractions.  The two frames add into the same registers.
 
-template <int CFA, int NF>
-__global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
+// FR = HR pixels per kernel-parameter / flow texel: 4 (the Bayer pipeline: fields at LR/2) or 2 (the monochrome pipeline:
+// fields at LR; 130 x 4 texels per tile, four texel columns per strip); the certainty mask is at LR/2 either way.
+template <int CFA, int NF, int FR = 4>
+__global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR = 2: 41 / 49 KB of LDS, three workgroups per CU
     k_accumulate2xTile(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
                        Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked,
                        int tilesX, int tilesY, int tilesPerXcd, int fresh, int tileY0)
@@ -673,8 +675,10 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     if (tile >= tilesX * tilesY) return;  // whole workgroup (uniform), before any barrier
     const int bIdYrel = tile / tilesX, bIdX = tile - bIdYrel * tilesX;
     const int bIdY = bIdYrel + tileY0;  // tileY0: first tile row of this launch's HR row window
-    __shared__ float4 sK[3][TILE_COLS];  // .w = 1 if the texel is PSD and finite, else 0
-    __shared__ float2 sF[NF][3][TILE_COLS];
+    static_assert(FR == 4 || FR == 2, "field resolution");
+    constexpr int FC = 256 / FR + 2, FROWS = 4 / FR + 2;  // field texels a tile touches: 66 x 3 (FR = 4), 130 x 4 (FR = 2)
+    __shared__ float4 sK[FROWS][FC];  // .w = 1 if the texel is PSD and finite, else 0
+    __shared__ float2 sF[NF][FROWS][FC];
     __shared__ float4 sM[NF][3][TILE_COLS];
     __shared__ __attribute__((aligned(16))) float sColA[256];  // x fraction per HR column of the tile, -1 = not on the predicted texel
     __shared__ float sRowB[4];                                 // y fraction per HR row of the tile, -1 likewise
@@ -688,11 +692,34 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     const int Y = bIdY * 4 + ly;
     const int hrW = 2 * dimX, hrH = 2 * dimY;
     const int X0 = 4 * tx;
-    const int fw = kernelParam.width, fh = kernelParam.height;  // == hrW/4, hrH/4 (checked on the host)
+    const int fw = kernelParam.width, fh = kernelParam.height;  // == hrW/FR, hrH/FR (checked on the host)
     const int mw = dimX / 2, mh = dimY / 2;                       // certainty mask size
     {
         const int t = ly * 64 + lx;
-        if (t < 3 * TILE_COLS) {
+        if constexpr (FR != 4) {
+            // fields and certainty on different grids: two staging loops
+            for (int i = t; i < FROWS * FC; i += 256) {
+                const int r = i / FC, c = i - r * FC;
+                const int gy = bIdY * (4 / FR) - 1 + r, gx = bIdX * (256 / FR) - 1 + c;
+                const int fy = clampi(gy, 0, fh - 1), fx = clampi(gx, 0, fw - 1);
+                float4 k = row_ptr((const float4*)kernelParam.ptr, kernelParam.pitch, fy)[fx];
+                k.w = psd_ok(k.x, k.y, k.z) ? 1.0f : 0.0f;
+                sK[r][c] = k;
+#pragma unroll
+                for (int n = 0; n < NF; n++) sF[n][r][c] = row_ptr((const float2*)fr.f[n].shifts.ptr, fr.f[n].shifts.pitch, fy)[fx];
+            }
+            if (t < 3 * TILE_COLS) {
+                const int r = t / TILE_COLS, c = t - r * TILE_COLS;
+                const int gy = bIdY - 1 + r, gx = bIdX * 64 - 1 + c;
+#pragma unroll
+                for (int n = 0; n < NF; n++) {
+                    const float4 m = row_ptr(fr.f[n].mask, strideMask, clampi(gy, 0, mh - 1))[clampi(gx, 0, mw - 1)];
+                    const float mc[3] = {sane(m.x), sane(m.y), sane(m.z)};
+                    sM[n][r][c] = make_float4(mc[Cfa<CFA>::col(0, 0)], mc[Cfa<CFA>::col(0, 1)], mc[Cfa<CFA>::col(1, 0)],
+                                              mc[Cfa<CFA>::col(1, 1)]);
+                }
+            }
+        } else if (t < 3 * TILE_COLS) {
             const int r = t / TILE_COLS, c = t - r * TILE_COLS;
             const int gy = bIdY - 1 + r, gx = bIdX * 64 - 1 + c;
             const int fy = clampi(gy, 0, fh - 1), fx = clampi(gx, 0, fw - 1);
@@ -717,7 +744,8 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
             float xB = posX * (float)fw - 0.5f;
             if (!finitef(xB)) xB = 0.0f;
             const float fxf = floorf(xB);
-            const int txc = X >> 2, ci = (t & 3) < 2 ? 0 : 1;
+            // texel column floor(xB) as predicted: (X / FR) - 1 for the first half of a texel's pixels, X / FR for the second
+            const int txc = FR == 4 ? X >> 2 : X >> 1, ci = FR == 4 ? ((t & 3) < 2 ? 0 : 1) : (t & 1);
             const bool ok = (f2i(fxf) == txc - 1 + ci) && (txc + ci <= fw - 1);
             sColA[t] = ok ? xB - fxf : -1.0f;
         }
@@ -727,8 +755,8 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
             float yB = posY * (float)fh - 0.5f;
             if (!finitef(yB)) yB = 0.0f;
             const float fyf = floorf(yB);
-            const int frr = t < 2 ? 0 : 1;  // LDS row of texel row floor(yB)
-            const bool ok = (f2i(fyf) == bIdY - 1 + frr) && f2i(fyf) >= 0 && f2i(fyf) + 1 <= fh - 1;
+            const int frr = FR == 4 ? (t < 2 ? 0 : 1) : (t + 1) >> 1;  // LDS row of texel row floor(yB)
+            const bool ok = (f2i(fyf) == bIdY * (4 / FR) - 1 + frr) && f2i(fyf) >= 0 && f2i(fyf) + 1 <= fh - 1;
             sRowB[t] = ok ? yB - fyf : -1.0f;
         }
     }
@@ -761,7 +789,10 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     if (!rowLive) return;
     const bool stripLive = X0 >= STRIP_MARGIN && X0 < hrW - STRIP_MARGIN;
 
-    const int fr_ = ly < 2 ? 0 : 1;
+    const int fr_ = FR == 4 ? (ly < 2 ? 0 : 1) : (ly + 1) >> 1;
+    constexpr int SC = FR == 4 ? 3 : 4;                               // texel columns a strip touches
+    const int cb = FR == 4 ? lx : 2 * lx;                             // LDS column of the first of them
+    auto ciOf = [](int k) { return FR == 4 ? (k < 2 ? 0 : 1) : (k + 1) >> 1; };  // left texel of pixel k's pair
     const float b = sRowB[ly];
     const float4 av4 = ((const float4*)sColA)[lx];
     const float av[4] = {av4.x, av4.y, av4.z, av4.w};
@@ -771,15 +802,17 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     float kxa[4], kya[4], kza[4];
     bool kOk;
     {
-        float4 Kt[2][3];
+        float4 Kt[2][SC];
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) Kt[r][c] = sK[fr_ + r][lx + c];
-        kOk = ((Kt[0][0].w * Kt[0][1].w) * (Kt[0][2].w * Kt[1][0].w)) * (Kt[1][1].w * Kt[1][2].w) > 0.0f;
+            for (int c = 0; c < SC; c++) Kt[r][c] = sK[fr_ + r][cb + c];
+        float kAll = ((Kt[0][0].w * Kt[0][1].w) * (Kt[0][2].w * Kt[1][0].w)) * (Kt[1][1].w * Kt[1][2].w);
+        if (SC == 4) kAll *= Kt[0][SC - 1].w * Kt[1][SC - 1].w;
+        kOk = kAll > 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int ci = k < 2 ? 0 : 1;
+            const int ci = ciOf(k);
             // same four bilinear weights as the flow, summed with fma (no rounding step depends on them)
             const float w00 = (1.0f - av[k]) * (1.0f - b), w10 = av[k] * (1.0f - b), w01 = (1.0f - av[k]) * b, w11 = av[k] * b;
             auto mix = [&](float t00, float t10, float t01, float t11) {
@@ -798,7 +831,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     uint32_t safeBits = 0;  // bit n: frame n took the fast path
     static_assert(NF <= 2 || TILE_PIXEL_MAJOR, "three and four frames per launch exist in pixel-major order only");
 #if TILE_PIXEL_MAJOR
-    if constexpr (NF > 1) {
+    if constexpr (NF > 1 || FR != 4) {
         // Two frames, pixel-major: the 13 tap weights of a pixel (12 v_exp_f32 and their exponents: a fifth of the
         // pixel's arithmetic) depend on the kernel parameters only, so each pixel takes them ONCE and applies them to
         // both frames before the next pixel starts -- 13 live registers instead of the 4 x 13 a frame-major loop would
@@ -807,15 +840,15 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
         uint32_t sxy[NF][4];
 #pragma unroll
         for (int n = 0; n < NF; n++) {
-            float2 Ft[2][3];
+            float2 Ft[2][SC];
 #pragma unroll
             for (int r = 0; r < 2; r++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) Ft[r][c] = sF[n][fr_ + r][lx + c];
+                for (int c = 0; c < SC; c++) Ft[r][c] = sF[n][fr_ + r][cb + c];
             bool safe = geomOk && kOk;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int ci = k < 2 ? 0 : 1;
+                const int ci = ciOf(k);
                 const float ux = lerp4(Ft[0][ci].x, Ft[0][ci + 1].x, Ft[1][ci].x, Ft[1][ci + 1].x, av[k], b);
                 const float uy = lerp4(Ft[0][ci].y, Ft[0][ci + 1].y, Ft[1][ci].y, Ft[1][ci + 1].y, av[k], b);
                 const int sx = round2i(ux * 2.0f), sy = round2i(uy * 2.0f);
@@ -996,7 +1029,7 @@ __global__ void __launch_bounds__(256, TILE_WAVES_NF(NF))
     using No = std::false_type;
     // staged accumulators must have landed before anyone reads them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    constexpr bool valueSumsStaged = TILE_PIXEL_MAJOR && NF > 1;  // the pixel-major loop has added them already
+    constexpr bool valueSumsStaged = TILE_PIXEL_MAJOR && (NF > 1 || FR != 4);  // the pixel-major loop has added them already
     if constexpr (PL == 2) {
         if (!valueSumsStaged) add_plane(0, accP);
         add_plane(1, accW);
@@ -1442,13 +1475,21 @@ bool tile_kernel_ok(mfsr_tex2d kp, mfsr_tex2d sh, int dimX, int dimY)
            (dimX % 4) == 0 && (dimY % 4) == 0 && g_strip_use_tile == 1;
 }
 
-template <int CFA, int NF>
+// the same for fields at HR/2 (the monochrome pipeline: tracking at the raw resolution)
+bool tile_kernel_ok_fr2(mfsr_tex2d kp, mfsr_tex2d sh, int dimX, int dimY)
+{
+    const int hrW = 2 * dimX, hrH = 2 * dimY;
+    return kp.width == sh.width && kp.height == sh.height && kp.width * 2 == hrW && kp.height * 2 == hrH && kp.width >= 4 &&
+           (dimX % 4) == 0 && (dimY % 4) == 0 && g_strip_use_tile == 1;
+}
+
+template <int CFA, int NF, int FR = 4>
 void launch_tile(dim3 grid, dim3 block, hipStream_t st, const TileFrames<NF>& fr, pix3* imgOut, pix3* tw, mfsr_tex2d kp,
                  Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int fresh, int tileY0)
 {
     const int tilesX = (int)grid.x, tilesY = (int)grid.y;
     const int tilesPerXcd = g_strip_xcd_remap ? mfsr_cdiv(tilesX * tilesY, 8) : 0;
-    hipLaunchKernelGGL((k_accumulate2xTile<CFA, NF>), dim3(tilesPerXcd ? 8 * tilesPerXcd : tilesX * tilesY), block, 0, st, fr,
+    hipLaunchKernelGGL((k_accumulate2xTile<CFA, NF, FR>), dim3(tilesPerXcd ? 8 * tilesPerXcd : tilesX * tilesY), block, 0, st, fr,
                        imgOut, tw, kp, glv, lv, dimX, dimY, strideOut, strideMask, cfaPacked, tilesX, tilesY, tilesPerXcd, fresh, tileY0);
 }
 
@@ -1570,10 +1611,14 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
     // two to four frames in one pass over the accumulators: the LDS tile kernel's geometry only
     bool pair = nFrames >= 2;
     for (int n = 0; n < nFrames; n++) pair = pair && tile_kernel_ok(kernelParam, shifts[n], dimX, dimY);
+    // the monochrome pipeline (fields at the raw resolution = HR/2): its own instantiation of the tile kernel, one or two frames
+    constexpr int kMono = pack_cfa(MFSR_GREEN, MFSR_GREEN, MFSR_GREEN, MFSR_GREEN);
+    bool mono2 = packed2 == kMono && nFrames <= 2;
+    for (int n = 0; n < nFrames; n++) mono2 = mono2 && tile_kernel_ok_fr2(kernelParam, shifts[n], dimX, dimY);
     if (nFrames > 2 && !pair) return 0;  // the caller splits the group
     // fresh accumulators ("as if zeroed", never read): the tile kernels write every row outside the top
     // and bottom margin bands themselves, the bands are zeroed here; the other kernels get a full memset
-    const bool tileFirst = pair || (nFrames == 1 && tile_kernel_ok(kernelParam, shifts[0], dimX, dimY));
+    const bool tileFirst = pair || mono2 || (nFrames == 1 && tile_kernel_ok(kernelParam, shifts[0], dimX, dimY));
     int tileFresh = 0;
     if (fresh) {
         if (tileFirst) {
@@ -1620,6 +1665,34 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
             (void)hipStreamWaitEvent(st, msx->join, 0);
         }
     };
+    if (mono2) {
+        auto launch_mono = [&](auto nfTag) {
+            constexpr int NF = decltype(nfTag)::value;
+            TileFrames<NF> fr;
+            for (int n = 0; n < NF; n++) {
+                fr.f[n].raw = dataIn[n];
+                fr.f[n].mask = (const float4*)certaintyMask[n];
+                fr.f[n].shifts = shifts[n];
+            }
+            launch_tile<kMono, NF, 2>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY, strideOut, strideMask, cp, tileFresh,
+                                      rowBlock0);
+            if (NF == 1) {
+                launch_margin(0);
+                return;
+            }
+            const int M = STRIP_MARGIN;
+            const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
+            hipLaunchKernelGGL((k_accumulateMarginN<NF, 2>), dim3(mfsr_cdiv(cnt, 64)), dim3(64, NF), 0, mst, fr, pI, pT, kernelParam, glv,
+                               dimX, dimY, strideOut, strideMask, cp, rowBegin, rowEnd);
+            if (msx) {
+                (void)hipEventRecord(msx->join, msx->stream);
+                (void)hipStreamWaitEvent(st, msx->join, 0);
+            }
+        };
+        if (nFrames == 1) launch_mono(std::integral_constant<int, 1>{});
+        if (nFrames == 2) launch_mono(std::integral_constant<int, 2>{});
+        return 1;
+    }
 #define STRIP_CASE(a, b, c, d)                                                                                         \
     case pack_cfa(a, b, c, d):                                                                                         \
         if (pair) {                                                                                                    \

@@ -245,7 +245,7 @@ def test_accumulate_x2_two_frames_per_call(orc, hip, pat, field):
 
 @pytest.mark.parametrize("fresh", [0, 1])
 @pytest.mark.parametrize("n,field,s,pat", [(3, "quarter", 2, "RGGB"), (4, "quarter", 2, "RGGB"), (4, "quarter", 2, "GBRG"),
-                                           (4, "quarter", 2, "MONO"), (3, "half", 2, "RGGB"), (4, "quarter", 4, "RGGB")])
+                                           (4, "quarter", 2, "MONO"), (3, "half", 2, "RGGB"), (3, "half", 2, "MONO"), (4, "quarter", 4, "RGGB")])
 def test_accumulate_groups_of_three_and_four(orc, hip, n, field, s, pat, fresh):
     """mfsr_accumulateSuperResFullN with 3 / 4 frames == that many oracle calls in the same order.  x2 with quarter-resolution
     fields: ONE launch of the LDS tile kernel (pixel-major, tap weights once per pixel, one plane-set staged at a time)
