@@ -221,7 +221,7 @@ extern "C" int mfsr_accumulateSuperResFull2(const uint16_t* dataIn0, const uint1
                                         scale, strideOut, strideMask, 0, stream);
 }
 
-// nFrames (1 or 2) frames in one call; accumulatorsUndefined != 0: the planes are overwritten as if
+// nFrames (1 .. MFSR_MAX_FUSE_GROUP) frames in one call; accumulatorsUndefined != 0: the planes are overwritten as if
 // they had been zeroed before the call (the first launch of a burst: saves the memset and the read of
 // both planes -- 0 + x == x, so the result equals the zeroed-and-accumulated one bit for bit).
 // Only HR rows [rowBegin, rowEnd) are touched (stripe-sharded bursts): rowBegin a multiple of 16, rowEnd a multiple

@@ -2,7 +2,7 @@
 // restructured for CDNA4.  Same mathematics as accumulateImagesSuperRes (reference
 // test_opencv/DeBayerKernels.cu:379-468, full-frame generalisation), accumulators in HBM as in the
 // reference (48 B per HR pixel and frame in its one-launch-per-frame structure; these kernels also take
-// two frames per launch and move them once for both).
+// up to four frames per launch and move the accumulators once for all of them).
 //
 // Why not the straight port (accumulate.hip): it spends its time in VALU/SALU work, not in HBM -- per tap
 // an IEEE division, a 3-way colour branch and a 16-byte certainty load (1.67 ms per 4K frame = 13 % of
@@ -17,7 +17,9 @@
 //    sum((raw-b)/wl * w*c) = (sum(raw*w*c) - b*sum(w*c)) / wl.
 //  * no colour branches: sites are summed per CFA-position class (row/column parity relative to the first
 //    site); classes map to R/G/B once per pixel (the CFA pattern is a template parameter).
-//  * 12 exponentials per pixel instead of 25: w(px,py) = w(-px,-py), v_exp_f32, exponents from sums.
+//  * 12 exponentials per pixel instead of 25: w(px,py) = w(-px,-py), v_exp_f32, exponents from sums -- and, with
+//    several frames per launch, once per pixel for all of them (pixel-major order: the weights depend on the kernel
+//    parameters of the reference only).
 //  * LDS tile kernels (fields at the tracking resolution): field / certainty texels, interpolation
 //    fractions and the accumulator rows (LDS-DMA) staged per workgroup; see k_accumulate2xTile.
 //
@@ -648,11 +650,12 @@ __global__ void __launch_bounds__(256)
 #define TILE_GROUP_BOTH_PLANES 1
 #endif
 #define TILE_WAVES_NF(NF) ((NF) == 1 ? TILE_WAVES : ((NF) > 2 && TILE_GROUP_BOTH_PLANES) ? 3 : TILE_WAVES2)
-// two frames per launch: pixel-major order with the tap weights shared by both frames (0: frame-major, weights per frame)
+// several frames per launch: pixel-major order with the tap weights shared by the frames (0: frame-major, weights per
+// frame; two frames at most)
 #ifndef TILE_PIXEL_MAJOR
 #define TILE_PIXEL_MAJOR 1
 #endif
-// NF frames per launch (1 or 2).  Everything that does not depend on the frame is done once for
+// NF frames per launch (1 to 4).  Everything that does not depend on the frame is done once for
 // both: the accumulator staging and write-back (the 48 B/px/frame of HBM traffic become 24), the
 // kernel-parameter mix, the column/row fractions.  The two frames add into the same registers.
 
