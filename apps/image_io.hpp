@@ -1,6 +1,7 @@
 // image_io.hpp -- image file I/O of the CLI tools (the reference uses cv::imread / cv::imwrite,
 // finalProject/Project/multi_frame_sr.cpp:172,207-209): 8-bit PNG (zlib) read + write, binary PGM/PPM read, baseline JPEG
-// read (jpeg_baseline.hpp: the "car" burst).  Host code only.
+// read (jpeg_baseline.hpp: the "car" burst), uncompressed 8 / 16-bit TIFF read (raw-like inputs, test_opencv/main.cpp:346-368).
+// Host code only.
 #pragma once
 #include <zlib.h>
 
@@ -15,7 +16,8 @@
 
 struct Image8 {
     int w = 0, h = 0, ch = 0;
-    std::vector<uint8_t> px;
+    std::vector<uint8_t> px;      // 8 bits per sample (for 16-bit sources: the high bytes)
+    std::vector<uint16_t> px16;   // 16-bit sources only: the full samples, same layout
 };
 
 static uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | p[1] << 16 | p[2] << 8 | p[3]; }
@@ -133,9 +135,96 @@ static bool read_jpeg(const std::string& path, Image8& img)
     return jpegb::decode_jpeg(buf, img.w, img.h, img.ch, img.px);
 }
 
+// Baseline TIFF (classic, II or MM): first image, uncompressed, chunky, 8 or 16 bits per sample, 1 / 3 / 4 samples per
+// pixel, any strip layout.  Everything else (LZW / deflate, tiles, planar, BigTIFF) is refused.
+static bool read_tiff(const std::string& path, Image8& img)
+{
+    std::vector<uint8_t> buf;
+    if (!read_file(path, buf) || buf.size() < 8) return false;
+    const bool le = buf[0] == 'I' && buf[1] == 'I', be = buf[0] == 'M' && buf[1] == 'M';
+    if (!le && !be) return false;
+    auto u16 = [&](size_t o) -> uint32_t { return o + 2 <= buf.size() ? (le ? buf[o] | buf[o + 1] << 8 : buf[o] << 8 | buf[o + 1]) : 0; };
+    auto u32 = [&](size_t o) -> uint32_t {
+        if (o + 4 > buf.size()) return 0;
+        return le ? (uint32_t)buf[o] | (uint32_t)buf[o + 1] << 8 | (uint32_t)buf[o + 2] << 16 | (uint32_t)buf[o + 3] << 24
+                  : (uint32_t)buf[o] << 24 | (uint32_t)buf[o + 1] << 16 | (uint32_t)buf[o + 2] << 8 | (uint32_t)buf[o + 3];
+    };
+    if (u16(2) != 42) return false;
+    const size_t ifd = u32(4);
+    if (ifd == 0 || ifd + 2 > buf.size()) return false;
+    const uint32_t n = u16(ifd);
+    if (ifd + 2 + (size_t)n * 12 > buf.size()) return false;
+    uint32_t width = 0, height = 0, bits = 1, compression = 1, spp = 1, rowsPerStrip = 0xffffffffu, planar = 1;
+    std::vector<uint32_t> offsets, counts;
+    // value(s) of an entry: type 3 = SHORT, 4 = LONG; inline when they fit 4 bytes
+    auto values = [&](size_t e, std::vector<uint32_t>& out) {
+        const uint32_t type = u16(e + 2), cnt = u32(e + 4);
+        const size_t sz = type == 3 ? 2 : (type == 4 ? 4 : (type == 1 ? 1 : 0));
+        if (sz == 0 || cnt > (1u << 24)) return false;
+        const size_t base = (size_t)cnt * sz <= 4 ? e + 8 : u32(e + 8);
+        if (base + (size_t)cnt * sz > buf.size()) return false;
+        out.resize(cnt);
+        for (uint32_t i = 0; i < cnt; i++) out[i] = sz == 2 ? u16(base + 2 * i) : (sz == 4 ? u32(base + 4 * (size_t)i) : buf[base + i]);
+        return true;
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        const size_t e = ifd + 2 + (size_t)i * 12;
+        const uint32_t tag = u16(e);
+        std::vector<uint32_t> v;
+        if (tag != 256 && tag != 257 && tag != 258 && tag != 259 && tag != 273 && tag != 277 && tag != 278 && tag != 279 && tag != 284)
+            continue;
+        if (!values(e, v) || v.empty()) return false;
+        switch (tag) {
+            case 256: width = v[0]; break;
+            case 257: height = v[0]; break;
+            case 258:
+                bits = v[0];
+                for (uint32_t b : v)
+                    if (b != bits) return false;
+                break;
+            case 259: compression = v[0]; break;
+            case 273: offsets = v; break;
+            case 277: spp = v[0]; break;
+            case 278: rowsPerStrip = v[0]; break;
+            case 279: counts = v; break;
+            case 284: planar = v[0]; break;
+        }
+    }
+    if (width == 0 || height == 0 || width > 65535 || height > 65535 || compression != 1 || planar != 1) return false;
+    if ((bits != 8 && bits != 16) || (spp != 1 && spp != 3 && spp != 4) || offsets.empty()) return false;
+    if (rowsPerStrip == 0 || rowsPerStrip > height) rowsPerStrip = height;
+    const size_t rowBytes = (size_t)width * spp * (bits / 8);
+    const size_t strips = ((size_t)height + rowsPerStrip - 1) / rowsPerStrip;
+    if (offsets.size() < strips) return false;
+    img.w = (int)width;
+    img.h = (int)height;
+    img.ch = (int)spp;
+    img.px.resize((size_t)width * height * spp);
+    if (bits == 16) img.px16.resize(img.px.size());
+    else img.px16.clear();
+    for (size_t st = 0; st < strips; st++) {
+        const size_t y0 = st * rowsPerStrip, rows = y0 + rowsPerStrip <= height ? rowsPerStrip : height - y0;
+        const size_t need = rows * rowBytes;
+        if ((size_t)offsets[st] + need > buf.size() || (!counts.empty() && st < counts.size() && counts[st] < need)) return false;
+        const uint8_t* src = buf.data() + offsets[st];
+        const size_t o = y0 * (size_t)width * spp, cnt = rows * (size_t)width * spp;
+        if (bits == 8) {
+            memcpy(&img.px[o], src, cnt);
+        } else {
+            for (size_t i = 0; i < cnt; i++) {
+                const uint16_t v = le ? (uint16_t)(src[2 * i] | src[2 * i + 1] << 8) : (uint16_t)(src[2 * i] << 8 | src[2 * i + 1]);
+                img.px16[o + i] = v;
+                img.px[o + i] = (uint8_t)(v >> 8);
+            }
+        }
+    }
+    return true;
+}
+
 static bool read_image(const std::string& path, Image8& img)
 {
-    return read_png(path, img) || read_pnm(path, img) || read_jpeg(path, img);
+    img.px16.clear();
+    return read_png(path, img) || read_pnm(path, img) || read_jpeg(path, img) || read_tiff(path, img);
 }
 
 static void put32(std::vector<uint8_t>& v, uint32_t x)

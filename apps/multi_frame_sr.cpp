@@ -103,7 +103,7 @@ int main(int argc, char** argv)
     for (int i = 0; i < num_images; i++) {
         snprintf(buf, sizeof(buf), filenameFormat.c_str(), i + firstIndex);
         if (!read_image(buf, imgs[i])) {
-            fprintf(stderr, "cannot read frame %d of '%s' (%s): PNG, binary PNM or baseline JPEG expected\n", i, inputName.c_str(), buf);
+            fprintf(stderr, "cannot read frame %d of '%s' (%s): PNG, binary PNM, baseline JPEG or uncompressed TIFF expected\n", i, inputName.c_str(), buf);
             return 1;
         }
         printf("%s, [%d x %d]\n", buf, imgs[i].w, imgs[i].h);
@@ -118,15 +118,21 @@ int main(int argc, char** argv)
         return 1;
     }
 
-    // re-mosaic 8-bit RGB (or gray) to a 12-bit RGGB raw frame
+    // re-mosaic 8-bit RGB (or gray) to a 12-bit RGGB raw frame; 16-bit sources (TIFF) keep their upper 12 bits, and a
+    // single-channel 16-bit frame IS the raw frame (an RGGB mosaic as the sensor delivers it)
+    bool wide = !imgs[0].px16.empty();
+    for (int k = 0; k < num_images; k++)
+        if (wide != !imgs[k].px16.empty() || imgs[k].ch != imgs[0].ch) {
+            fprintf(stderr, "frames differ in sample depth or channel count\n");
+            return 1;
+        }
     std::vector<std::vector<uint16_t>> raws(num_images, std::vector<uint16_t>((size_t)W * H));
     for (int k = 0; k < num_images; k++)
         for (int y = 0; y < H; y++)
             for (int x = 0; x < W; x++) {
-                const uint8_t* p = &imgs[k].px[((size_t)y * imgs[k].w + x) * imgs[k].ch];
-                const int c = (y & 1) + (x & 1);  // RGGB
-                const int v = imgs[k].ch >= 3 ? p[c] : p[0];
-                raws[k][(size_t)y * W + x] = (uint16_t)(v * 16);
+                const size_t o = ((size_t)y * imgs[k].w + x) * imgs[k].ch;
+                const int c = imgs[k].ch >= 3 ? (y & 1) + (x & 1) : 0;  // RGGB
+                raws[k][(size_t)y * W + x] = wide ? (uint16_t)(imgs[k].px16[o + c] >> 4) : (uint16_t)(imgs[k].px[o + c] * 16);
             }
 
     mfsr_config cfg;
@@ -134,11 +140,12 @@ int main(int argc, char** argv)
     cfg.lkIterations = iterations;
     cfg.preAlign = 1;  // hand-held bursts: base shift + rotation per frame before the tile tracker (the bundled city frames
                        // are rotated by up to 15 degrees, test_opencv/main.cpp:1896)
+    const float whiteLevel = wide ? 4095.0f : 4080.0f;  // 255 * 16, or the 12 bits kept of a 16-bit sample
     for (int c = 0; c < 3; c++) {
         cfg.black[c] = 0.0f;
-        cfg.white[c] = 4080.0f;
+        cfg.white[c] = whiteLevel;
     }
-    cfg.maxVal = 4080.0f;
+    cfg.maxVal = whiteLevel;
     const size_t wsBytes = mfsr_burst_workspace_bytes(&cfg), accBytes = mfsr_burst_accumulator_bytes(&cfg);
     void *ws = nullptr, *imgOut = nullptr, *weights = nullptr, *outF = nullptr;
     HIP_OK(hipMalloc(&ws, wsBytes));

@@ -109,6 +109,122 @@ def test_image_readers_against_an_independent_decoder(tmp_path):
     assert subprocess.run([conv, str(bad), str(tmp_path / "x.ppm")], capture_output=True).returncode != 0
 
 
+def _tiff_bytes(arr, big_endian, rows_per_strip):
+    """Hand-written baseline TIFF (uncompressed, chunky) of a uint8 / uint16 array [h, w] or [h, w, c], several strips."""
+    import struct
+    e = ">" if big_endian else "<"
+    h, w = arr.shape[:2]
+    c = 1 if arr.ndim == 2 else arr.shape[2]
+    bits = arr.dtype.itemsize * 8
+    data = arr.astype(arr.dtype.newbyteorder(e)).tobytes()
+    row = w * c * bits // 8
+    strips = [(y, min(rows_per_strip, h - y)) for y in range(0, h, rows_per_strip)]
+    n = len(strips)
+    entries = []
+    extra = b""
+    ifd_off = 8 + len(data)
+    n_entries = 9
+    extra_off = ifd_off + 2 + n_entries * 12 + 4
+
+    def entry(tag, typ, vals):
+        nonlocal extra
+        sz = {3: 2, 4: 4}[typ]
+        raw = b"".join(struct.pack(e + {3: "H", 4: "I"}[typ], v) for v in vals)
+        if len(raw) <= 4:
+            val = raw.ljust(4, b"\0")
+        else:
+            val = struct.pack(e + "I", extra_off + len(extra))
+            extra += raw
+        entries.append(struct.pack(e + "HHI", tag, typ, len(vals)) + val)
+
+    entry(256, 4, [w])
+    entry(257, 4, [h])
+    entry(258, 3, [bits] * c)
+    entry(259, 3, [1])
+    entry(262, 3, [1 if c == 1 else 2])
+    entry(273, 4, [8 + y * row for y, _ in strips])
+    entry(277, 3, [c])
+    entry(278, 4, [rows_per_strip])
+    entry(279, 4, [r * row for _, r in strips])
+    assert len(entries) == n_entries
+    head = (b"MM" if big_endian else b"II") + struct.pack(e + "HI", 42, ifd_off)
+    return head + data + struct.pack(e + "H", n_entries) + b"".join(entries) + struct.pack(e + "I", 0) + extra
+
+
+def test_tiff_reader_against_numpy_and_pil(tmp_path):
+    """The CLI's TIFF reader (apps/image_io.hpp: classic TIFF, II / MM, uncompressed, 8 / 16 bit, 1 / 3 samples, any strip
+    layout) through apps/imgconv: hand-written files decode to the array they were made from, files written by PIL
+    (its own strip layout) likewise; compressed files are refused."""
+    from PIL import Image
+    conv = os.path.join(ROOT, "apps", "imgconv")
+    if not os.path.exists(conv):
+        pytest.skip("apps/imgconv not built")
+    r = np.random.default_rng(5)
+
+    def decode(path):
+        out = tmp_path / "o.pnm"
+        subprocess.check_call([conv, str(path), str(out)])
+        raw = open(out, "rb").read()
+        magic, dims, maxv, body = raw.split(b"\n", 3)
+        w, h = (int(v) for v in dims.split())
+        c = 1 if magic == b"P5" else 3
+        a = np.frombuffer(body, dtype=">u2" if int(maxv) == 65535 else np.uint8).reshape(h, w, c)
+        return a.astype(np.int64)[..., 0] if c == 1 else a.astype(np.int64)
+
+    cases = [(r.integers(0, 65536, (37, 53), dtype=np.uint16), True, 5), (r.integers(0, 65536, (40, 31, 3), dtype=np.uint16), True, 7),
+             (r.integers(0, 65536, (29, 64), dtype=np.uint16), False, 29), (r.integers(0, 256, (33, 47, 3), dtype=np.uint8), False, 4),
+             (r.integers(0, 256, (16, 16), dtype=np.uint8), True, 100)]
+    for arr, be, rps in cases:
+        f = tmp_path / "t.tif"
+        f.write_bytes(_tiff_bytes(arr, be, rps))
+        np.testing.assert_array_equal(decode(f), arr.astype(np.int64))
+    # PIL's writer: 8-bit RGB and 16-bit gray, large enough for several strips
+    rgb = r.integers(0, 256, (300, 420, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "p8.tif")
+    np.testing.assert_array_equal(decode(tmp_path / "p8.tif"), rgb.astype(np.int64))
+    g16 = r.integers(0, 65536, (260, 333), dtype=np.uint16)
+    Image.fromarray(g16).save(tmp_path / "p16.tif")
+    np.testing.assert_array_equal(decode(tmp_path / "p16.tif"), g16.astype(np.int64))
+    # compressed / truncated: refused, no crash
+    Image.fromarray(rgb).save(tmp_path / "lzw.tif", compression="tiff_lzw")
+    assert subprocess.run([conv, str(tmp_path / "lzw.tif"), str(tmp_path / "x.ppm")], capture_output=True).returncode != 0
+    (tmp_path / "cut.tif").write_bytes(_tiff_bytes(cases[0][0], True, 5)[:600])
+    assert subprocess.run([conv, str(tmp_path / "cut.tif"), str(tmp_path / "x.ppm")], capture_output=True).returncode != 0
+
+
+@pytest.mark.gpu
+def test_cli_reads_tiff_frames(tmp_path):
+    """The bundled city burst as TIFF files (the reference's fixed file names, content sniffed like cv::imread does): 8-bit
+    RGB TIFFs give exactly the PNG run's result; 16-bit single-channel TIFFs are taken as raw RGGB frames (upper 12 bits)
+    and give the same picture up to the white level (4095 instead of 255 * 16)."""
+    import shutil
+    from PIL import Image
+    assert os.path.exists(CLI)
+    src = os.path.join(ROOT, "tests", "golden", "city")
+    runs = {}
+    for kind in ("png", "tif8", "raw16"):
+        d = tmp_path / kind
+        d.mkdir()
+        for i in range(5):
+            im = np.asarray(Image.open(os.path.join(src, f"img_{i:06d}.png")).convert("RGB"))
+            dst = d / f"img_{i:06d}.png"
+            if kind == "png":
+                shutil.copy(os.path.join(src, f"img_{i:06d}.png"), dst)
+            elif kind == "tif8":
+                dst.write_bytes(_tiff_bytes(im, False, 17))
+            else:
+                yy, xx = np.mgrid[0:im.shape[0], 0:im.shape[1]]
+                mosaic = np.take_along_axis(im, ((yy & 1) + (xx & 1))[..., None], 2)[..., 0].astype(np.uint16) * 16   # 12-bit RGGB
+                dst.write_bytes(_tiff_bytes((mosaic << 4).astype(np.uint16), True, 64))
+        p = subprocess.run([CLI, "farneback", "city", "3"], cwd=d, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        runs[kind] = np.asarray(Image.open(d / "city_farneback_sr_result.png")).astype(np.int64)
+    assert np.array_equal(runs["png"], runs["tif8"])
+    d = np.abs(runs["png"] - runs["raw16"])
+    # white level 4095 vs 4080: -0.4 % in value everywhere; a few pixels sit on the other side of a flow rounding / threshold
+    assert d.mean() < 0.6 and (d > 3).mean() < 2e-3, (d.max(), d.mean(), (d > 3).mean())
+
+
 @pytest.mark.gpu
 def test_cli_car_burst_from_jpeg(tmp_path):
     """`multi_frame_sr farneback car 3` on the reference's own car/1..4.jpg (multi_frame_sr.cpp:155-159): decodes the JPEGs,
