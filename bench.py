@@ -453,6 +453,11 @@ def main():
         if os.path.exists(tpath):
             try:
                 ent = json.load(open(tpath)).get(args.workload)
+                # the counters were taken on whole-frame launches of one grouping: they say nothing about a stripe-sharded
+                # run (row_frac < 1) or another --group
+                if isinstance(ent, dict) and (row_frac != 1.0 or (ent.get("frames_per_launch") is not None and
+                                                                  abs(ent["frames_per_launch"] - frames_per_launch) > 0.01)):
+                    ent = None
                 if isinstance(ent, dict):
                     traffic = ent.get("hbm_bytes_per_launch")
                     vi = ent.get("valu_wave_insts_per_launch")

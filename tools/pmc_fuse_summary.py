@@ -35,7 +35,16 @@ for wl in wls:
     hbm = 2 * fetch * 1024 + write * 1024
     mk = re.search(r"k_\w+", k)
     kname = mk.group(0) if mk else k
-    res[wl] = {"hbm_bytes_per_launch": int(hbm), "valu_wave_insts_per_launch": int(valu),
+    # frames per launch of the profiled run (bench.py's own line in the pass log): bench.py applies the entry only to runs
+    # with the same grouping
+    fpl = None
+    try:
+        for ln in open(f"{root}/{wl}/p1.log"):
+            if ln.startswith("{") and '"roofline"' in ln:
+                fpl = json.loads(ln)["roofline"].get("frames_per_launch")
+    except Exception:
+        fpl = None
+    res[wl] = {"hbm_bytes_per_launch": int(hbm), "valu_wave_insts_per_launch": int(valu), "frames_per_launch": fpl,
                "source": f"rocprofv3 --pmc passes of tools/gpu_pmc_workloads.sh ({kname}: {n_main} dispatches + "
                          f"{n_margin} margin dispatches per burst)"}
     lines.append(f"{wl}: kernel {k[:90]}")
