@@ -591,7 +591,9 @@ __global__ void __launch_bounds__(256)
     const pix3 val = row_ptr(finalImg, imgPitch, y)[x];
     const pix3 w = row_ptr(weight, imgPitch, y)[x];
     pix3 inout = {0.0f, 0.0f, 0.0f};
-    if (fallback) {
+    // ApplyWeighting reads the fallback only where a weight is under the threshold (kernel.cu:444-462): the resample (12
+    // loads, two divisions, the bilinear mix: 40 % of this kernel's instructions) is skipped by the waves that need none
+    if (fallback && (w.x < threshold || w.y < threshold || w.z < threshold)) {
         const float u = u0 + (u1 - u0) * (((float)x + 0.5f) / (float)width);
         // row y of this launch is row y + rowOffset of a fullHeight-row image: the same float expression as the whole-image
         // launch evaluates for that row, so a stripe-wise finish is bit-identical to the whole one
