@@ -196,6 +196,7 @@ static bool read_tiff(const std::string& path, Image8& img)
     const size_t rowBytes = (size_t)width * spp * (bits / 8);
     const size_t strips = ((size_t)height + rowsPerStrip - 1) / rowsPerStrip;
     if (offsets.size() < strips) return false;
+    if ((size_t)height * rowBytes > buf.size()) return false;  // uncompressed: the samples are in the file, or the header lies
     img.w = (int)width;
     img.h = (int)height;
     img.ch = (int)spp;
