@@ -36,7 +36,9 @@
 // 7x7 window the warped region (58 x 26 = 1508 samples) is 1.96 rounds of the 768 threads, where a
 // 32-wide tile needs 3 rounds of 512 for 2.13 (the warp is half of the kernel's instructions); TX = 32
 // serves images narrower than 48 + 2h + 4.
+#ifndef LK_TY
 #define LK_TY 16
+#endif
 
 // reflection about the image edges for -n <= i < 2n (the tile halo never reaches further):
 // ... 1 0 | 0 1 ... n-1 | n-1 n-2 ...   (no integer division)
