@@ -141,6 +141,76 @@ def cpu_baseline(W, H, s, mono, sample_frames, seed):
     return res
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def spawn_ranks(n, argv, extra_env=None, timeout_s=None):
+    """`python3 bench.py --gpus N` without a launcher: this parent makes NO GPU call (it never imports torch); it starts
+    N fresh child processes of this same script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would), relays rank 0's JSON line, and returns non-zero if any child fails (the others are then
+    terminated by their exact PIDs).  Returns (rc, rank-0 stdout)."""
+    import subprocess
+    port = _free_port()
+    timeout_s = timeout_s or float(os.environ.get("MFSR_BENCH_RANK_TIMEOUT_S", "900"))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "MFSR_BENCH_CHILD": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    t_end = time.time() + timeout_s
+    rc, out0 = 0, ""
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+        if live and (rc != 0 or time.time() > t_end):
+            if rc == 0:
+                rc = 124
+                print(f"bench.py: ranks {sorted(live)} still running after {timeout_s:.0f} s", file=sys.stderr)
+            time.sleep(2.0 if rc != 124 else 0.0)        # a failing rank usually takes its peers down with it
+            for r in sorted(live):
+                if procs[r].poll() is None:
+                    procs[r].terminate()
+            for r in sorted(live):
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            live.clear()
+            break
+        if live:
+            if 0 not in live:
+                time.sleep(0.05)
+            else:
+                try:                                       # drain rank 0's pipe while waiting (one JSON line, but be safe)
+                    o, _ = procs[0].communicate(timeout=0.2)
+                    out0 += o or ""
+                except subprocess.TimeoutExpired:
+                    pass
+    if procs[0].stdout and not procs[0].stdout.closed:
+        try:
+            out0 += procs[0].stdout.read() or ""
+        except Exception:
+            pass
+    return rc, out0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,9 +222,14 @@ def main():
     ap.add_argument("--exchange", default="stripes", choices=["stripes", "auto", "reduce", "reduce_scatter"],
                     help="N > 1: stripes (default: p2p exchange of LR products, fuse sharded over HR row stripes, bit-identical "
                          "to 1 GPU), reduce (north_star's wording: accumulators onto rank 0), reduce_scatter")
-    ap.add_argument("--dist-impl", default="rccl", choices=["rccl", "torch"],
-                    help="N > 1: rccl = the C-ABI multi-GPU layer (libmfsr_dist.so, RCCL directly); torch = its torch.distributed "
-                         "mirror (distributed.py; also what MFSR_DIST_BACKEND=gloo rehearsals use)")
+    ap.add_argument("--dist-impl", default="rccl", choices=["rccl", "torch", "local"],
+                    help="N > 1: rccl = the C-ABI multi-GPU layer (libmfsr_dist.so), one process per GPU, RCCL directly; torch = its "
+                         "torch.distributed mirror (distributed.py; also what MFSR_DIST_BACKEND=gloo rehearsals use); local = the "
+                         "same C-ABI layer with all N ranks in THIS process (mfsr_dist_group_*: one thread per rank, peer copies)")
+    ap.add_argument("--virtual-ranks", action="store_true",
+                    help="--dist-impl local: all N ranks on device 0 (functional rehearsal on a one-GPU box, not a measurement)")
+    ap.add_argument("--dry-run-ranks", action="store_true",
+                    help="(test hook) every rank prints its launch environment as JSON and exits without touching the GPU")
     ap.add_argument("--force-dist", action="store_true", help="N=1: run the step through mfsr_dist_* (one-rank communicator) -- rehearsal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the H2D->D2H end-to-end leg (median of 20 bursts)")
@@ -175,16 +250,40 @@ def main():
                          "stream (the PCIe-inclusive rate quoted in DESIGN.md; `value` of the contract is the HBM-resident run)")
     args = ap.parse_args()
 
+    local_group = args.dist_impl == "local" and args.gpus > 1
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not local_group:
+        # plain `python3 bench.py --gpus N`: start the N ranks ourselves (before anything here touches the GPU)
+        rc, out0 = spawn_ranks(args.gpus, sys.argv[1:])
+        if rc != 0 and args.dist_impl == "rccl" and not args.dry_run_ranks and os.environ.get("MFSR_BENCH_NO_FALLBACK") != "1":
+            # the one-process-per-GPU RCCL run failed: measure the same sharded burst with all ranks in ONE fresh process
+            # (mfsr_dist_group_*, peer copies) rather than report nothing; the line says which transport ran and why
+            print(f"bench.py: the RCCL run failed (rc {rc}); falling back to --dist-impl local in a fresh process", file=sys.stderr)
+            import subprocess
+            env = dict(os.environ, MFSR_BENCH_FALLBACK_FROM=f"rccl run failed with rc {rc}")
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--dist-impl", "local"], env=env,
+                               stdout=subprocess.PIPE, text=True,
+                               timeout=float(os.environ.get("MFSR_BENCH_RANK_TIMEOUT_S", "900")))
+            rc, out0 = p.returncode, p.stdout
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        raise SystemExit(rc)
+
+    world = 1 if local_group else int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0")) if not local_group else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if not local_group else 0
+    if args.dry_run_ranks:
+        fail_rank = os.environ.get("MFSR_BENCH_FAIL_RANK")
+        if fail_rank is not None and int(fail_rank) == rank:
+            raise SystemExit(3)
+        print(json.dumps({"dry_run": True, "rank": rank, "local_rank": local_rank, "world": world, "gpus": args.gpus,
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+                          "child": os.environ.get("MFSR_BENCH_CHILD") == "1"}), flush=True)
+        return
+
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if world != args.gpus and not local_group:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
@@ -209,7 +308,8 @@ def main():
 
     W, H, fpg, s, mono = WORKLOADS[args.workload]
     strong = not args.weak           # N > 1: the workload's burst is fixed and sharded (north_star: ">= 6x at 8 GPUs vs 1")
-    n_frames = fpg if strong else fpg * world
+    n_ranks = args.gpus if local_group else world      # ranks of the burst (local group: all of them in this process)
+    n_frames = fpg if strong else fpg * n_ranks
     cfg = default_config(W, H, n_frames, s, mono)
     cfg.fused = 0 if args.unfused else 1
     if args.no_pair:
@@ -218,7 +318,7 @@ def main():
         cfg.pairFrames = args.group
     if args.no_async_fuse:
         cfg.asyncFuse = 0
-    if world == 1:
+    if world == 1 and not local_group:
         # device slots for --h2d and the end-to-end leg (mfsr_burst_*_host); unused by the resident run.  16 slots (the
         # maximum): a whole 16-frame burst uploads without waiting for a slot (11.2 ms per 4K burst incl. the download of the
         # result, against 14.9 / 15.6 ms with 4 / 8 slots; 8K x 8 is PCIe-bound at 19.2 ms whatever the depth,
@@ -229,20 +329,42 @@ def main():
     # --force-dist: the multi-GPU code path with a world of one rank (one-rank RCCL communicator): rehearsal of what the
     # driver's N > 1 runs execute, on a single GPU
     use_cabi_dist = (world > 1 or args.force_dist) and dist_impl == "rccl"
-    pipe = None if use_cabi_dist else BurstPipeline(cfg, dev)
+    pipe = None if (use_cabi_dist or local_group) else BurstPipeline(cfg, dev)
+    if local_group:
+        args.no_e2e = True
     if use_cabi_dist and world == 1:
         args.no_e2e = True
 
     # synthetic burst: one scene (same seed on every rank), this rank's frames only
     seed = 1234 + 2
-    mine = mdist.frames_of_rank(n_frames, rank, world)
-    ref_frames, _, _ = make_burst(W, H, 1, scale=s, mono=mono, seed=seed, device=dev)
-    shard, _, _ = make_burst(W, H, len(mine), scale=s, mono=mono, seed=seed, device=dev, shift_seed=seed + 100 + rank,
-                             first_is_reference=False)
-    frames = {k: shard[i] for i, k in enumerate(mine)}
-    frames[cfg.reference] = ref_frames[0]
-    del shard
+
+    def rank_frames(r, device):
+        own = mdist.frames_of_rank(n_frames, r, n_ranks)
+        ref_frames, _, _ = make_burst(W, H, 1, scale=s, mono=mono, seed=seed, device=device)
+        shard, _, _ = make_burst(W, H, len(own), scale=s, mono=mono, seed=seed, device=device, shift_seed=seed + 100 + r,
+                                 first_is_reference=False)
+        fr = {k: shard[i] for i, k in enumerate(own)}
+        fr[cfg.reference] = ref_frames[0]
+        return own, fr
+
+    mine, frames = rank_frames(rank, dev)
     torch.cuda.synchronize()
+
+    # --dist-impl local: all ranks of the burst in this process (mfsr_dist_group_*: one worker thread per rank inside the
+    # library, peer copies over xGMI in place of RCCL calls; the same per-rank code as the RCCL contexts)
+    grp = None
+    if local_group:
+        n_dev = torch.cuda.device_count()
+        if not args.virtual_ranks and n_dev < n_ranks:
+            raise SystemExit(f"--dist-impl local --gpus {n_ranks}: only {n_dev} device(s) visible (--virtual-ranks puts every rank "
+                             "on device 0: a functional rehearsal)")
+        g_devices = [0] * n_ranks if args.virtual_ranks else list(range(n_ranks))
+        per_rank = [frames] + [rank_frames(r, torch.device("cuda", g_devices[r]))[1] for r in range(1, n_ranks)]
+        grp = mdist.LocalGroup(cfg, g_devices)
+        g_table = grp.frame_table(per_rank)
+        g_mode = "stripes" if args.exchange == "auto" else args.exchange
+        for d_i in sorted(set(g_devices)):
+            torch.cuda.synchronize(d_i)
 
     # N > 1, C-ABI path: one mfsr_dist context per rank (RCCL communicator + burst context + per-frame product buffers);
     # a step is one mfsr_dist_process_burst on the current stream
@@ -299,6 +421,9 @@ def main():
     def step():
         if h2d:
             return step_h2d()
+        if grp is not None:
+            grp.process(g_table, g_mode)
+            return grp.out16
         if use_cabi_dist:
             D.dist_process_burst(d_h, d_ptrs, d_mode, d_out16.data_ptr() if d_out16 is not None else None, d_status.data_ptr(),
                                  torch.cuda.current_stream().cuda_stream)
@@ -329,6 +454,9 @@ def main():
         return out
 
     def barrier():
+        if grp is not None:
+            grp.synchronize()   # every rank's streams idle (the last burst's stripes are on rank 0)
+            return
         if use_cabi_dist:   # the last burst's stripes are collected on the dist context's own stream
             D.dist_wait_output(d_h, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
@@ -344,6 +472,15 @@ def main():
         step()
     barrier()
     halo_note = None
+    if grp is not None and g_mode == "stripes":
+        if args.warmup == 0:
+            step()
+            barrier()
+        if any(int(t.item()) != 0 for t in grp.status):
+            grp.set_raw_halo(H)
+            halo_note = "whole raw frames exchanged (a flow exceeded the default 64-row halo)"
+            step()
+            barrier()
     if use_cabi_dist and exchange == "stripes":
         # a vertical flow beyond the raw halo of the stripes exchange (status 1) invalidates the result: exchange whole raw
         # frames instead (always valid, ~2.5x the traffic); decided on a probe burst outside the timed region
@@ -360,7 +497,8 @@ def main():
             barrier()
     from multi_frame_super_resolution_amd import capi as _capi
     LIB = _capi.lib()
-    timed_bursts = [q._h for q in pipes] + ([dctx["burst"]] if dctx else [])
+    # (local group: rank 0's burst context is the one whose warp+fuse launches are event-timed)
+    timed_bursts = [q._h for q in pipes] + ([dctx["burst"]] if dctx else []) + ([grp.burst_handle(0)] if grp is not None else [])
     for hb in timed_bursts:
         LIB.burst_timing(hb, 1)
     t0 = time.perf_counter()
@@ -381,6 +519,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if grp is not None and any(int(t.item()) != 0 for t in grp.status):
+        raise SystemExit("mfsr_dist: a frame's vertical flow exceeded the raw halo of the stripes exchange (status 1)")
     if use_cabi_dist and int(d_status.item()) != 0:
         raise SystemExit("mfsr_dist: a frame's vertical flow exceeded the raw halo of the stripes exchange (status 1): the result is "
                          "invalid; use --exchange reduce_scatter or a larger halo")
@@ -434,12 +574,12 @@ def main():
         # bytes a launch MUST move (accumulators once per launch, not once per frame) vs the reference-structure figure
         # frames fused per rank and the fraction of the HR rows a launch covers: all frames on 1/world of the rows in the
         # stripes mode, the rank's own frames on the whole grid otherwise
-        stripes_mode = (world > 1 or use_cabi_dist) and exchange == "stripes"
+        stripes_mode = (n_ranks > 1 or use_cabi_dist) and exchange == "stripes"
         fused_per_rank = n_frames if stripes_mode else len(mine)
         row_frac = 1.0
         if stripes_mode:
             pl = _capi.StripePlan()
-            LIB.dist_stripe_plan(ctypes.byref(cfg), world, 0, 64, ctypes.byref(pl))
+            LIB.dist_stripe_plan(ctypes.byref(cfg), n_ranks, 0, 64, ctypes.byref(pl))
             row_frac = (pl.rowEnd - pl.rowBegin) / float(H * s)
         n_launch_burst, bytes_burst = burst_fuse_bytes(W, H, s, mono, fused_per_rank, int(LIB.raw["mfsr_burst_group_size"](ctypes.byref(cfg))))
         bytes_launch = bytes_burst / n_launch_burst * row_frac
@@ -476,7 +616,7 @@ def main():
             "metric": "Mpix/s end-to-end (N-frame burst -> x2 SR)" if s == 2 else f"Mpix/s end-to-end (N-frame burst -> x{s} SR)",
             "value": round(value, 2),
             "unit": "Mpix/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
@@ -492,16 +632,23 @@ def main():
                 "frames_per_gpu": len(mine),
                 "burst_frames": n_frames,
                 "output_mpix_per_s": round(s * s * W * H * args.steps / dt / 1e6, 2),
-                "parallelism": "1 GPU" if world == 1 else (
-                    (f"align frame-sharded x{world}, p2p exchange of the LR products (raw/flow/certainty rows), fuse sharded over "
-                     f"{world} HR row stripes, u16 stripes gathered on rank 0 (bit-identical to 1 GPU)" if exchange == "stripes" else
-                     f"frame-shard x{world} + RCCL {exchange} of the HR accumulators"
+                "parallelism": "1 GPU" if n_ranks == 1 else (
+                    (f"align frame-sharded x{n_ranks}, p2p exchange of the LR products (one packed message of raw/flow/certainty rows "
+                     f"per peer), fuse sharded over {n_ranks} HR row stripes, u16 stripes gathered on rank 0 (bit-identical to 1 GPU)"
+                     if exchange == "stripes" else
+                     f"frame-shard x{n_ranks} + {exchange} of the HR accumulators"
                      + (" overlapped with the next burst's compute" if pipelined else ""))
-                    + (", libmfsr_dist.so (RCCL directly)" if use_cabi_dist else ", torch.distributed mirror")
-                    + (f"; {halo_note}" if halo_note else "")),
+                    + (", libmfsr_dist.so, one process per GPU (RCCL directly)" if use_cabi_dist else
+                       (", libmfsr_dist.so, all ranks in one process (mfsr_dist_group: one thread per rank, peer copies)"
+                        + (", ALL RANKS ON DEVICE 0: rehearsal, not a measurement" if args.virtual_ranks else "")
+                        if grp is not None else ", torch.distributed mirror"))
+                    + (f"; {halo_note}" if halo_note else "")
+                    + (f"; fallback: {os.environ['MFSR_BENCH_FALLBACK_FROM']}" if os.environ.get("MFSR_BENCH_FALLBACK_FROM") else "")),
                 "kernels": "unfused (one launch per reference kernel)" if args.unfused else "fused",
                 **({"rehearsal": "gloo backend, ranks share GPUs, collectives staged through the host: not a measurement"}
                    if (world > 1 and backend == "gloo") else {}),
+                **({"exchange_per_rank": [dict(zip(("messages_sent", "bytes_sent"), grp.exchange_stats(r))) for r in range(n_ranks)]}
+                   if grp is not None else {}),
             },
             "end_to_end": e2e,
             "roofline": {
@@ -539,7 +686,7 @@ def main():
                 },
             },
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and n_ranks == 1:
             line["cpu_baseline"] = cpu_baseline(W, H, s, mono, args.cpu_sample_frames, seed)
         else:
             line["cpu_baseline"] = None
@@ -547,6 +694,8 @@ def main():
 
     for q in pipes:
         q.close()
+    if grp is not None:
+        grp.close()
     if dctx:
         dctx["D"].dist_destroy(dctx["h"])
     if world > 1:

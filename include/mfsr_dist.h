@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 enum { MFSR_DIST_STRIPES = 0, MFSR_DIST_REDUCE = 1, MFSR_DIST_REDUCE_SCATTER = 2 };
-#define MFSR_E_COMM (-5)        /* an RCCL call failed (logged to stderr) */
+#define MFSR_E_COMM (-5)        /* a transport call failed: RCCL error, or a peer of a local group failed / timed out (logged) */
 #define MFSR_DIST_ID_BYTES 128  /* sizeof(ncclUniqueId) */
 #define MFSR_DIST_DEFAULT_RAW_HALO 64
 
@@ -68,6 +68,37 @@ int mfsr_dist_process_burst(mfsr_dist* d, const uint16_t* const* frames, int mod
  * process_burst are complete once `stream` has passed mfsr_dist_wait_output (or after a device-wide synchronise).
  * MFSR_DIST_OVERLAP=0 in the environment keeps every call on the caller's stream. */
 int mfsr_dist_wait_output(mfsr_dist* d, mfsr_stream_t stream);
+/* "rccl" or "local": the transport behind d (see below) */
+const char* mfsr_dist_transport(const mfsr_dist* d);
+/* messages and bytes this rank SENT during the last mfsr_dist_process_burst (exchange + stripe gather; the collectives of
+ * the reduce modes and the one-int status all-reduce are not counted).  STRIPES: one packed message per peer whose stripe
+ * is not empty (+ one stripe to rank 0), whatever the number of frames. */
+int mfsr_dist_exchange_stats(const mfsr_dist* d, long long* messagesSent, long long* bytesSent);
+
+/* ---- G ranks inside ONE process ("local" transport) -------------------------------------------------------------------
+ * The reference's entry point is one process with one thread (finalProject/Project/multi_frame_sr.cpp:122-210); a drop-in
+ * of it cannot start one process per GPU.  mfsr_dist_group runs the SAME per-rank code as mfsr_dist_create's contexts
+ * (csrc/dist.cpp: process_stripes / process_reduce / gather_stripes behind one transport table) with one worker thread
+ * per rank and peer copies (hipMemcpyPeerAsync, ordered by events after a host-side rendezvous) in place of RCCL calls.
+ * devices[r] = HIP device of rank r (NULL: every rank on the current device).  Several ranks may share a device
+ * ("virtual ranks"): that is how the multi-rank code is exercised on a one-GPU box.  workspaces[r]: workspaceBytes >=
+ * mfsr_dist_workspace_bytes(cfg, worldSize) device bytes on devices[r], 256-byte aligned. */
+typedef struct mfsr_dist_group mfsr_dist_group;
+int mfsr_dist_group_create(mfsr_dist_group** out, const mfsr_config* cfg, int worldSize, const int* devices, void* const* workspaces,
+                           size_t workspaceBytes);
+void mfsr_dist_group_destroy(mfsr_dist_group* g);
+mfsr_dist* mfsr_dist_group_rank(mfsr_dist_group* g, int rank); /* owned by g */
+int mfsr_dist_group_set_raw_halo(mfsr_dist_group* g, int rawHalo);
+/* One burst on all ranks.  frames: worldSize x cfg->frames table (row r = the `frames` argument of mfsr_dist_process_burst
+ * for rank r: pointers on devices[r]); out16 on devices[0]; status: per-rank device ints (or NULL); streams: per-rank
+ * streams (or NULL: streams the group owns -- ranks sharing a device must NOT share a stream, and never the NULL stream).
+ * Returns when every rank has ENQUEUED its burst (asynchronous like mfsr_dist_process_burst). */
+int mfsr_dist_group_process_burst(mfsr_dist_group* g, const uint16_t* const* frames, int mode, uint16_t* out16, int* const* status,
+                                  const mfsr_stream_t* streams);
+/* every rank's stream waits for the last burst's output (mfsr_dist_wait_output per rank) */
+int mfsr_dist_group_wait_output(mfsr_dist_group* g, const mfsr_stream_t* streams);
+/* blocks the host until every rank's streams (the given ones, or the group's own) and comm streams are idle */
+int mfsr_dist_group_synchronize(mfsr_dist_group* g, const mfsr_stream_t* streams);
 
 #ifdef __cplusplus
 }

@@ -78,7 +78,7 @@ _BY_VALUE = {
     "mfsr_stream_t": ctypes.c_void_p, "long long": ctypes.c_longlong,
 }
 _RET = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "void": None, "const char*": ctypes.c_char_p,
-        "mfsr_burst*": ctypes.c_void_p}
+        "mfsr_burst*": ctypes.c_void_p, "mfsr_dist*": ctypes.c_void_p}
 
 
 def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[str, List[Tuple[str, str]]]]:
@@ -92,7 +92,7 @@ def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[str, List[Tuple[str
     text = re.sub(r"\{[^{}]*\}", " ", text)                    # struct / enum bodies
     protos = {}
     for stmt in text.split(";"):
-        m = re.match(r"^\s*((?:const\s+char\s*\*|mfsr_burst\s*\*|int|size_t|void))\s+(mfsr_\w+)\s*\((.*)\)\s*$", stmt, flags=re.S)
+        m = re.match(r"^\s*((?:const\s+char\s*\*|mfsr_burst\s*\*|mfsr_dist\s*\*|int|size_t|void))\s+(mfsr_\w+)\s*\((.*)\)\s*$", stmt, flags=re.S)
         if not m:
             continue
         ret = re.sub(r"\s+", " ", m.group(1)).replace(" *", "*").strip()

@@ -264,3 +264,77 @@ def process_burst(pipe, frames, mode: str = "auto", group=None, n_frames: Option
         return process_burst_stripes(pipe, frames, None, group, n_frames)[0]
     accumulate_local(pipe, frames, dist.get_rank(group), dist.get_world_size(group), n_frames)
     return exchange_and_finish(pipe, mode, group)
+
+
+class LocalGroup:
+    """``mfsr_dist_group_*`` (include/mfsr_dist.h): G ranks of a burst inside ONE process, one worker thread per rank in
+    the library, peer copies in place of RCCL calls -- the same per-rank code as the RCCL contexts (csrc/dist.cpp).
+    ``devices[r]`` = HIP device index of rank r; several ranks may share a device ("virtual ranks": how the multi-rank
+    code is exercised on a one-GPU box)."""
+
+    MODES = {"stripes": 0, "reduce": 1, "reduce_scatter": 2}
+
+    def __init__(self, cfg, devices: Sequence[int]):
+        import ctypes
+
+        from . import capi
+        self._ct = ctypes
+        self.D = capi.dist_lib()
+        self.cfg = cfg
+        self.world = len(devices)
+        self.devices = [int(d) for d in devices]
+        nbytes = self.D.dist_workspace_bytes(ctypes.byref(cfg), self.world)
+        if nbytes == 0:
+            raise ValueError("mfsr_dist_workspace_bytes: invalid configuration")
+        self._ws = [torch.empty(nbytes + 256, dtype=torch.uint8, device=f"cuda:{d}") for d in self.devices]
+        bases = (ctypes.c_void_p * self.world)(*[(w.data_ptr() + 255) // 256 * 256 for w in self._ws])
+        devs = (ctypes.c_int * self.world)(*self.devices)
+        self._h = ctypes.c_void_p()
+        self.D.dist_group_create(ctypes.byref(self._h), ctypes.byref(cfg), self.world, devs, bases, nbytes)
+        s, W, H = cfg.scale, cfg.width, cfg.height
+        self.out16 = torch.zeros(H * s, W * s, 3, dtype=torch.int16, device=f"cuda:{self.devices[0]}")
+        self.status = [torch.zeros(1, dtype=torch.int32, device=f"cuda:{d}") for d in self.devices]
+        self._status_ptrs = (ctypes.c_void_p * self.world)(*[t.data_ptr() for t in self.status])
+
+    def rank_handle(self, r: int):
+        return self.D.raw["mfsr_dist_group_rank"](self._h, r)
+
+    def burst_handle(self, r: int):
+        return self.D.raw["mfsr_dist_burst"](self.rank_handle(r))
+
+    def set_raw_halo(self, halo: int):
+        self.D.dist_group_set_raw_halo(self._h, int(halo))
+
+    def frame_table(self, per_rank_frames):
+        """per_rank_frames[r] = mapping frame number -> raw tensor ON devices[r] (the rank's own frames + the reference)."""
+        ct, N = self._ct, self.cfg.frames
+        tab = (ct.c_void_p * (self.world * N))()
+        for r in range(self.world):
+            for k in range(N):
+                t = per_rank_frames[r].get(k)
+                tab[r * N + k] = t.data_ptr() if t is not None else None
+        return tab
+
+    def process(self, table, mode: str = "stripes"):
+        """One burst on the group's own per-rank streams; returns after every rank has enqueued it."""
+        self.D.dist_group_process_burst(self._h, table, self.MODES[mode], self.out16.data_ptr(), self._status_ptrs, None)
+
+    def synchronize(self):
+        self.D.dist_group_synchronize(self._h, None)
+
+    def exchange_stats(self, r: int):
+        ct = self._ct
+        m, b = ct.c_longlong(0), ct.c_longlong(0)
+        self.D.dist_exchange_stats(self.rank_handle(r), ct.byref(m), ct.byref(b))
+        return m.value, b.value
+
+    def close(self):
+        if self._h:
+            self.D.dist_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
