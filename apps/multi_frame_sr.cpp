@@ -16,6 +16,10 @@
 //     window and times the second half; here every replay is one whole burst and
 //     the second half of the replays is timed (same warm-up/timed split, :146-149,:188-206).
 //   * image I/O (apps/image_io.hpp): PNG (zlib), binary PGM/PPM and baseline JPEG (the "car" burst) in, PNG out.
+//   * MFSR_GPUS=n in the environment (argv stays the reference's) shards the burst over n GPUs from this ONE process:
+//     mfsr_dist_group (include/mfsr_dist.h) -- one worker thread per GPU inside the library, alignment sharded over
+//     frames, fuse over HR row stripes, peer copies over xGMI; the u16 result is bit-identical to the 1-GPU burst.
+//     MFSR_VIRTUAL_RANKS=1 puts all n ranks on device 0 (test rehearsal on a one-GPU box).
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -27,6 +31,7 @@
 #include <vector>
 
 #include "../include/mfsr.h"
+#include "../include/mfsr_dist.h"
 #include "image_io.hpp"
 
 #define HIP_OK(x)                                                                   \
@@ -146,6 +151,87 @@ int main(int argc, char** argv)
         cfg.white[c] = whiteLevel;
     }
     cfg.maxVal = whiteLevel;
+    const int hrW = W * scale, hrH = H * scale;
+    const int start_i = num_times - real_times;
+    std::chrono::steady_clock::time_point t0;
+    std::vector<uint8_t> h8((size_t)hrW * hrH * 3), h8s(h8.size());
+    uint8_t *d8 = nullptr, *d8s = nullptr;
+
+    int gpus = 1;
+    if (const char* e = getenv("MFSR_GPUS")) gpus = atoi(e);
+    if (gpus > 1) {
+        // ---- the burst sharded over `gpus` GPUs from this one process ------------------------------------------------
+        const bool virt = getenv("MFSR_VIRTUAL_RANKS") && getenv("MFSR_VIRTUAL_RANKS")[0] == '1';
+        if (!virt && mfsr_device_count() < gpus) {
+            fprintf(stderr, "MFSR_GPUS=%d but only %d HIP device(s) are visible\n", gpus, mfsr_device_count());
+            return 1;
+        }
+        std::vector<int> devs(gpus);
+        for (int r = 0; r < gpus; r++) devs[r] = virt ? 0 : r;
+        const size_t dwsBytes = mfsr_dist_workspace_bytes(&cfg, gpus);
+        if (!dwsBytes) {
+            fprintf(stderr, "mfsr_dist_workspace_bytes: invalid configuration\n");
+            return 1;
+        }
+        std::vector<void*> dws(gpus, nullptr);
+        std::vector<const uint16_t*> table((size_t)gpus * num_images, nullptr);  // row r: rank r's frames + the reference
+        std::vector<int*> dstatus(gpus, nullptr);
+        for (int r = 0; r < gpus; r++) {
+            HIP_OK(hipSetDevice(devs[r]));
+            HIP_OK(hipMalloc(&dws[r], dwsBytes));
+            HIP_OK(hipMalloc((void**)&dstatus[r], sizeof(int)));
+            for (int k = 0; k < num_images; k++) {
+                if (k % gpus != r && k != cfg.reference) continue;
+                uint16_t* p = nullptr;
+                HIP_OK(hipMalloc((void**)&p, (size_t)W * H * 2));
+                HIP_OK(hipMemcpy(p, raws[k].data(), (size_t)W * H * 2, hipMemcpyHostToDevice));  // :172 upload
+                table[(size_t)r * num_images + k] = p;
+            }
+        }
+        HIP_OK(hipSetDevice(devs[0]));
+        uint16_t* d16 = nullptr;
+        HIP_OK(hipMalloc((void**)&d16, (size_t)hrW * hrH * 6));
+        mfsr_dist_group* g = nullptr;
+        MFSR_OK_OR_DIE(mfsr_dist_group_create(&g, &cfg, gpus, devs.data(), dws.data(), dwsBytes));
+        bool wholeFrames = false;
+        for (int rep = 0; rep < num_times; rep++) {
+            if (rep == start_i) {
+                MFSR_OK_OR_DIE(mfsr_dist_group_synchronize(g, nullptr));
+                t0 = std::chrono::steady_clock::now();
+            }
+            MFSR_OK_OR_DIE(mfsr_dist_group_process_burst(g, table.data(), MFSR_DIST_STRIPES, d16, dstatus.data(), nullptr));
+            if (rep == 0 && !wholeFrames) {  // a flow beyond the raw halo of the stripe exchange: exchange whole raw frames
+                MFSR_OK_OR_DIE(mfsr_dist_group_synchronize(g, nullptr));
+                int st = 0;
+                HIP_OK(hipMemcpy(&st, dstatus[0], sizeof(int), hipMemcpyDeviceToHost));
+                if (st != 0) {
+                    MFSR_OK_OR_DIE(mfsr_dist_group_set_raw_halo(g, H));
+                    wholeFrames = true;
+                    rep = -1;
+                }
+            }
+        }
+        MFSR_OK_OR_DIE(mfsr_dist_group_synchronize(g, nullptr));
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("%g sec\n", sec);                                               // :205
+        printf("%g FPS\n", (double)(num_images * real_times) / sec);           // :206
+        std::vector<uint16_t> h16((size_t)hrW * hrH * 3);
+        HIP_OK(hipMemcpy(h16.data(), d16, h16.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h16.size(); i++) h8[i] = (uint8_t)(((unsigned)h16[i] * 255u + 32767u) / 65535u);
+        HIP_OK(hipMalloc((void**)&d8, h8.size()));
+        HIP_OK(hipMalloc((void**)&d8s, h8.size()));
+        HIP_OK(hipMemcpy(d8, h8.data(), h8.size(), hipMemcpyHostToDevice));
+        MFSR_OK_OR_DIE(mfsr_sharpenImg2(d8, d8s, hrH, hrW, 3, hrW * 3, hrW * 3, nullptr));
+        HIP_OK(hipMemcpy(h8s.data(), d8s, h8s.size(), hipMemcpyDeviceToHost));
+        mfsr_dist_group_destroy(g);
+        if (!write_png(inputName + "_" + optFlowName + "_sr_result.png", h8.data(), hrW, hrH, 3) ||   // :207
+            !write_png(inputName + "_" + optFlowName + "_sr2_result.png", h8s.data(), hrW, hrH, 3)) {  // :209
+            fprintf(stderr, "cannot write result PNGs\n");
+            return 1;
+        }
+        return 0;
+    }
+
     const size_t wsBytes = mfsr_burst_workspace_bytes(&cfg), accBytes = mfsr_burst_accumulator_bytes(&cfg);
     void *ws = nullptr, *imgOut = nullptr, *weights = nullptr, *outF = nullptr;
     HIP_OK(hipMalloc(&ws, wsBytes));
@@ -160,9 +246,6 @@ int main(int argc, char** argv)
     mfsr_burst* b = nullptr;
     MFSR_OK_OR_DIE(mfsr_burst_create(&b, &cfg, ws, wsBytes));
 
-    const int hrW = W * scale, hrH = H * scale;
-    const int start_i = num_times - real_times;
-    std::chrono::steady_clock::time_point t0;
     for (int rep = 0; rep < num_times; rep++) {
         if (rep == start_i) {
             HIP_OK(hipDeviceSynchronize());
@@ -183,12 +266,10 @@ int main(int argc, char** argv)
     printf("%g FPS\n", (double)(num_images * real_times) / sec);           // :206
 
     // result -> 8-bit RGB (D2H), then sharpenImg2 on the device
-    uint8_t *d8 = nullptr, *d8s = nullptr;
     HIP_OK(hipMalloc((void**)&d8, (size_t)hrW * hrH * 3));
     HIP_OK(hipMalloc((void**)&d8s, (size_t)hrW * hrH * 3));
     MFSR_OK_OR_DIE(mfsr_quantize((const mfsr_float3*)outF, 12 * hrW, nullptr, d8, hrW, hrH, 255.0f, nullptr));
     MFSR_OK_OR_DIE(mfsr_sharpenImg2(d8, d8s, hrH, hrW, 3, hrW * 3, hrW * 3, nullptr));
-    std::vector<uint8_t> h8((size_t)hrW * hrH * 3), h8s(h8.size());
     HIP_OK(hipMemcpy(h8.data(), d8, h8.size(), hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(h8s.data(), d8s, h8s.size(), hipMemcpyDeviceToHost));
     if (!write_png(inputName + "_" + optFlowName + "_sr_result.png", h8.data(), hrW, hrH, 3) ||   // :207

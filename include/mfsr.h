@@ -597,6 +597,9 @@ int mfsr_burst_timing_read(mfsr_burst* b, double* totalMs, int* launches, int* f
 int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2d* mask, mfsr_tex2d* kernelParam,
                            mfsr_tex2d* tracking);
 /* global pre-alignment of the last add_frame (cfg.preAlign), copied to HOST memory; synchronises the stream */
+/* products of the frame aligned `framesBack` frames before the last one (0 = the last: what mfsr_burst_debug_views gives).
+ * Valid while framesBack < 2 * MFSR_MAX_FUSE_GROUP (the ring of per-frame slots) and the burst has aligned that many. */
+int mfsr_burst_debug_frame_views(mfsr_burst* b, int framesBack, mfsr_tex2d* flow, mfsr_tex2d* mask);
 int mfsr_burst_prealign_result(mfsr_burst* b, mfsr_prealign* hostOut, mfsr_stream_t stream);
 
 #ifdef __cplusplus

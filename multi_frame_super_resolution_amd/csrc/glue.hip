@@ -17,7 +17,7 @@ extern "C" const char* mfsr_error_string(int code)
         case MFSR_E_UNSUPPORTED: return "unsupported parameter";
         case MFSR_E_NODEVICE: return "no HIP device";
         case MFSR_E_WORKSPACE: return "workspace too small";
-        case -5: return "RCCL call failed (mfsr_dist)";  // MFSR_E_COMM, include/mfsr_dist.h
+        case -5: return "multi-GPU transport failed (mfsr_dist: RCCL error, or a peer of a local group failed / timed out)";  // MFSR_E_COMM, include/mfsr_dist.h
         default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);

@@ -244,6 +244,8 @@ struct mfsr_burst {
     Img* flowCur;  // flow of the last add_frame (raw-pixel units)
     Img* maskCur;  // certainty mask of the last add_frame
     bool haveRef;
+    bool refStale;                      // the reference's alignment products were swapped away (process_joint): finish is
+                                        // still valid, aligning another frame needs a new set_reference
     // frame grouping (cfg.pairFrames): aligned frames wait here until their group is complete, then the
     // group is fused in one pass over the accumulators; flush/finish fuses what is left of a group
     struct Pending {
@@ -267,6 +269,7 @@ struct mfsr_burst {
     hipEvent_t evAligned[kRing];        // recorded on the caller's stream when slot's flow/mask are complete
     hipEvent_t evFused[kRing];          // recorded on fuseStream when the fuse that read the slot is done
     bool fusedOutstanding[kRing];       // evFused[slot] recorded and not yet waited for by the caller's stream
+    Img* slotFlow[kRing];               // which buffer of the slot's LK ping-pong pair holds the frame's final flow
     // host-frame bursts (cfg.uploadRing): copy stream, per-slot events, reference double buffer
     hipStream_t copyStream;
     hipStream_t downStream;                 // D2H of the finished image (mfsr_burst_finish_host), concurrent with the uploads
@@ -446,6 +449,7 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
         }
     }
     b->haveRef = false;
+    b->refStale = false;
     *out = b;
     return MFSR_OK;
 }
@@ -560,14 +564,19 @@ extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, m
     }
 
     // E: kernel shape field from the reference tracking image
-    if (c.fused) {
-        TRY(mfsr_structureTensorFused((const float*)L.refPyr[0].ptr, L.refPyr[0].pitch, (mfsr_float3*)L.tensor.ptr,
-                                      L.tensor.pitch, L.tw, L.th, stream));
-    } else {
-        TRY(mfsr_ComputeDerivatives2Kernel(L.tw, L.th, L.Ix.pitch, (float*)L.Ix.ptr, (float*)L.Iy.ptr, as_tex(L.refPyr[0]),
-                                           stream));
-        TRY(mfsr_ComputeStructureTensor((const float*)L.Ix.ptr, (const float*)L.Iy.ptr, (mfsr_float3*)L.tensor.ptr, L.tw,
-                                        L.th, L.Ix.pitch, L.tensor.pitch, stream));
+    // E1 + E2 run once per burst on an LR-sized image, and E3 turns their result into the kernel ORIENTATION through an
+    // eigen-decomposition that is ill-conditioned wherever the tensor is nearly isotropic (k1 != k2 even there,
+    // kernel.cu:766-772): a tensor that differs in its last bits (mfsr_structureTensorFused reads the texels directly
+    // instead of blending them with the ~1e-7 weights an exact-float bilinear fetch at a texel centre has) moves the tap
+    // exponents by up to 0.5 there, i.e. the accumulators by 1e-3 relative -- measured, tools/parity_audit.py.  So the
+    // fused pipeline also takes the bit-exact two-kernel chain here (+ ~10 us per burst); the derivative images borrow
+    // two Lucas-Kanade scratch planes, which no frame of this burst has touched yet.
+    {
+        Img& ix = c.fused ? L.lkSum[0] : L.Ix;
+        Img& iy = c.fused ? L.lkDiff[0] : L.Iy;
+        TRY(mfsr_ComputeDerivatives2Kernel(L.tw, L.th, ix.pitch, (float*)ix.ptr, (float*)iy.ptr, as_tex(L.refPyr[0]), stream));
+        TRY(mfsr_ComputeStructureTensor((const float*)ix.ptr, (const float*)iy.ptr, (mfsr_float3*)L.tensor.ptr, L.tw, L.th, ix.pitch,
+                                        L.tensor.pitch, stream));
     }
     TRY(mfsr_separableFilter((const float*)L.tensor.ptr, L.tensor.pitch, (float*)L.tensorTmp.ptr, (float*)L.tensorSm.ptr,
                              L.tensorSm.pitch, L.tw, L.th, 3, b->tensorTaps, b->ntensorTaps, stream));
@@ -590,6 +599,7 @@ extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, m
                                       L.fallback.pitch, bp, sc, stream));
     }
     b->haveRef = true;
+    b->refStale = false;
     return MFSR_OK;
 }
 
@@ -879,6 +889,7 @@ static int align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, int 
     }
     *flowOut = flow;
     *maskOut = mask;
+    b->slotFlow[slot] = flow;  // mfsr_burst_debug_frame_views
     return MFSR_OK;
 }
 
@@ -887,6 +898,7 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
 {
     MFSR_REQUIRE(b && raw && imgOut && totalWeights);
     MFSR_REQUIRE(b->haveRef);
+    MFSR_REQUIRE(!b->refStale);  // after mfsr_burst_process_joint: call mfsr_burst_set_reference first
     const mfsr_config& c = b->cfg;
     TRY(mfsr_set_cfa_pattern(c.cfa));
     const int slot = b->frameCounter++ % kRing;
@@ -933,6 +945,7 @@ extern "C" int mfsr_burst_align_frame(mfsr_burst* b, const uint16_t* raw, int is
 {
     MFSR_REQUIRE(b && raw && flowOut && maskOut);
     MFSR_REQUIRE(b->haveRef);
+    MFSR_REQUIRE(!b->refStale);  // after mfsr_burst_process_joint: call mfsr_burst_set_reference first
     Layout& L = b->L;
     MFSR_REQUIRE((long long)flowPitch >= 8LL * L.tw && (flowPitch & 7) == 0 && ((uintptr_t)flowOut & 7) == 0);
     MFSR_REQUIRE((long long)maskPitch >= 16LL * L.hw && (maskPitch & 15) == 0 && ((uintptr_t)maskOut & 15) == 0);
@@ -1218,6 +1231,16 @@ extern "C" int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2
     return MFSR_OK;
 }
 
+extern "C" int mfsr_burst_debug_frame_views(mfsr_burst* b, int framesBack, mfsr_tex2d* flow, mfsr_tex2d* mask)
+{
+    MFSR_REQUIRE(b != nullptr && framesBack >= 0 && framesBack < kRing && framesBack < b->frameCounter);
+    const int slot = (int)((b->frameCounter - 1 - framesBack) % kRing);
+    MFSR_REQUIRE(b->slotFlow[slot] != nullptr);
+    if (flow) *flow = as_tex(*b->slotFlow[slot]);
+    if (mask) *mask = as_tex(b->L.maskBuf[slot]);
+    return MFSR_OK;
+}
+
 extern "C" int mfsr_burst_prealign_result(mfsr_burst* b, mfsr_prealign* hostOut, mfsr_stream_t stream)
 {
     MFSR_REQUIRE(b && hostOut);
@@ -1293,6 +1316,7 @@ struct mfsr_stream {
     hipStream_t copyStream;
     hipEvent_t evUp, evWindow[64];   // evWindow[j % 64]: output j's work enqueued on the compute stream
     bool windowRecorded[64];
+    long long lastWindow;            // index of the last output whose evWindow was recorded (-1: none)
 };
 
 extern "C" size_t mfsr_stream_workspace_bytes(const mfsr_config* cfg, int radius)
@@ -1331,7 +1355,12 @@ extern "C" int mfsr_stream_create(mfsr_stream** out, const mfsr_config* cfg, int
     }
     s->imgOut = (mfsr_float3*)(base + s->S.offImg);
     s->totalWeights = (mfsr_float3*)(base + s->S.offTw);
+    s->lastWindow = -1;
     s->fp = new (std::nothrow) std::vector<FrameProducts>(s->cap);
+    if (!s->fp) {
+        mfsr_stream_destroy(s);
+        return MFSR_E_INVALID;
+    }
     for (int i = 0; i < s->cap; i++) stream_entry(&s->cfg, base + s->S.offEntries + s->S.entryBytes * (size_t)i, &(*s->fp)[i]);
     if (s->hostFrames) {
         hipError_t e = hipStreamCreateWithFlags(&s->copyStream, hipStreamNonBlocking);
@@ -1390,6 +1419,7 @@ static int stream_window(mfsr_stream* s, long long j, long long lo, long long hi
     if (s->copyStream) {
         MFSR_HIP_TRY(hipEventRecord(s->evWindow[j % 64], mfsr_s(stream)));
         s->windowRecorded[j % 64] = true;
+        s->lastWindow = j;
     }
     return MFSR_OK;
 }
@@ -1444,6 +1474,13 @@ extern "C" int mfsr_stream_drain(mfsr_stream* s, mfsr_float3* outImg, uint16_t* 
 extern "C" int mfsr_stream_reset(mfsr_stream* s)
 {
     MFSR_REQUIRE(s != nullptr);
+    // host-frame mode: the next push uploads into slot 0 on the copy stream, which the windows of the stream that is being
+    // abandoned may still read on the compute stream: order the copy stream after the last of them (they were enqueued in
+    // order), then forget their events -- index j of the new stream must not wait for output j of the old one
+    if (s->copyStream && s->lastWindow >= 0 && s->windowRecorded[s->lastWindow % 64])
+        MFSR_HIP_TRY(hipStreamWaitEvent(s->copyStream, s->evWindow[s->lastWindow % 64], 0));
+    for (int i = 0; i < 64; i++) s->windowRecorded[i] = false;
+    s->lastWindow = -1;
     s->pushed = s->produced = 0;
     return MFSR_OK;
 }
@@ -1585,6 +1622,7 @@ extern "C" int mfsr_burst_process_joint(mfsr_burst* b, const uint16_t* const* fr
         for (int l = 0; l < kMaxLevels; l++) L.refSq[l] = savedRefSq[l];
         b->refPrepared = b->movPrepared = false;
         b->givenShifts = nullptr;
+        b->refStale = true;  // L.refHalf / L.refPyr no longer belong to the reference set_reference saw
     };
     struct Guard {
         decltype(restore)& r;

@@ -14,7 +14,10 @@ plus, on the accumulated weights,
 implementations (the "flip set"); everywhere else the two outputs must agree to +-1 LSB with NO exception.
 A pixel is also put in the set when either side is within ``tie_eps`` of a rounding tie / of the threshold: the HIP
 kernels evaluate the same bilinear blend with the weights in another order (1 ulp), so a value that close to a tie
-may flip inside the kernel without showing in the recomputed roundings.
+may flip inside the kernel without showing in the recomputed roundings.  ``tie_eps`` = 2.5e-7 relative = two ulp: what that
+reorder can move (round 2 used 4e-6, which made the set ~4x the real flips; the sweep 4e-6 / 1e-6 / 2.5e-7 / 0 of
+tools/parity_audit.py leaves the outside-the-set statistics unchanged -- profiles/r03_parity_audit_*.log).  The report
+carries the set's size with and without the guard.
 """
 from __future__ import annotations
 
@@ -44,7 +47,7 @@ def _near_tie(v: np.ndarray, eps: float) -> np.ndarray:
 
 
 class FlipSet:
-    def __init__(self, cfg, tie_eps: float = 4e-6):
+    def __init__(self, cfg, tie_eps: float = 2.5e-7):
         from oracle.bindings import oracle
         self.o = oracle()
         self.c = cfg
@@ -54,6 +57,7 @@ class FlipSet:
         self.hrW, self.hrH = self.W * self.s, self.H * self.s
         self.tie_eps = tie_eps
         self.flips = np.zeros((self.hrH, self.hrW), bool)
+        self.flips_actual = np.zeros((self.hrH, self.hrW), bool)     # decisions that really differ (no tie guard)
         self.n = dict(fuse_round=0, fuse_round_actual=0, robust_round=0, robust_M=0, weight_threshold=0)
         self.frames = 0
         self.max_flow_diff = 0.0
@@ -85,6 +89,7 @@ class FlipSet:
         self.n["fuse_round"] += int(f1.sum())
         self.n["fuse_round_actual"] += int(a1.sum())
         self.flips |= f1
+        self.flips_actual |= a1
         # (2) + (3), half resolution
         rvh, rsh = self._robust_shifts(flow_h)
         rvo, rso = self._robust_shifts(flow_o)
@@ -95,11 +100,13 @@ class FlipSet:
         self.n["robust_round"] += int(f2.sum())
         self.n["robust_M"] += int(f3.sum())
         fm = f2 | f3
-        if fm.any():
-            # certainty site of HR pixel X, tap px: floor((X+px)/s)/2, px in [-2,2]  ->  half-res pixel x is read by
-            # X in [2s*x - 2, 2s*x + 2s + 1]
-            up = np.repeat(np.repeat(fm, 2 * self.s, 0), 2 * self.s, 1)[:self.hrH, :self.hrW]
-            self.flips[:up.shape[0], :up.shape[1]] |= _dilate(up, 2)
+        fm_actual = (rsh != rso).any(-1) | ((Mh > thr) != (Mo > thr))
+        for m, dst in ((fm, self.flips), (fm_actual, self.flips_actual)):
+            if m.any():
+                # certainty site of HR pixel X, tap px: floor((X+px)/s)/2, px in [-2,2]  ->  half-res pixel x is read by
+                # X in [2s*x - 2, 2s*x + 2s + 1]
+                up = np.repeat(np.repeat(m, 2 * self.s, 0), 2 * self.s, 1)[:self.hrH, :self.hrW]
+                dst[:up.shape[0], :up.shape[1]] |= _dilate(up, 2)
 
     def add_weights(self, tw_h, tw_o):
         """(4): the accumulated weights on either side of ApplyWeighting's threshold."""
@@ -107,6 +114,7 @@ class FlipSet:
         f4 = ((tw_h < thr) != (tw_o < thr)).any(-1)
         self.n["weight_threshold"] += int(f4.sum())
         self.flips |= f4
+        self.flips_actual |= f4
 
     def report(self, h_out, o_out, h16, o16):
         """Error statistics inside / outside the flip set (8 bit: the CLI's output depth; 16 bit as the finer diagnostic)."""
@@ -117,6 +125,8 @@ class FlipSet:
         tot = float(E.size)
         r = {
             "flip_fraction": float(E.sum()) / tot,
+            "flip_fraction_no_guard": float(self.flips_actual.sum()) / tot,
+            "tie_eps": self.tie_eps,
             "flips_by_cause_per_frame": {k: v / max(self.frames, 1) / tot for k, v in self.n.items()},
             "max_flow_diff_px": self.max_flow_diff,
             "max8_inside": int(d8[inside].max()) if inside.any() else 0,

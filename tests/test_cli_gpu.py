@@ -83,6 +83,33 @@ def test_cli_on_the_bundled_city_frames(tmp_path):
     pipe.close()
 
 
+@pytest.mark.gpu
+def test_cli_shards_the_burst_from_one_process(tmp_path):
+    """MFSR_GPUS=3 (argv unchanged): the CLI drives mfsr_dist_group from its one process -- here with the three ranks on
+    device 0 (MFSR_VIRTUAL_RANKS=1).  The bundled city frames are rotated by up to 15 degrees: vertical flows beyond the
+    default 64-row halo, so the run also takes the status-1 -> whole-raw-frames path.  Same picture as the 1-GPU CLI (the
+    u16 images are bit-identical, tests/test_dist_local_gpu.py; the two 8-bit quantisations may differ by one level where
+    the u16 value sits on a rounding boundary)."""
+    import shutil
+    from PIL import Image
+    from tests.test_bundled_burst import CITY
+    assert os.path.exists(CLI), "build apps/multi_frame_sr first (__graft_entry__.build())"
+    outs = []
+    for sub, env in (("one", {}), ("three", {"MFSR_GPUS": "3", "MFSR_VIRTUAL_RANKS": "1"})):
+        d = tmp_path / sub
+        d.mkdir()
+        for i in range(5):
+            shutil.copy(os.path.join(CITY, f"img_{i:06d}.png"), d / f"img_{i:06d}.png")
+        p = subprocess.run([CLI, "farneback", "city", "3"], cwd=d, capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr
+        assert " sec" in p.stdout and " FPS" in p.stdout
+        outs.append((np.asarray(Image.open(d / "city_farneback_sr_result.png")).astype(int),
+                     np.asarray(Image.open(d / "city_farneback_sr2_result.png")).astype(int)))
+    d0 = np.abs(outs[0][0] - outs[1][0])
+    print("1-GPU vs 3-rank CLI: max 8-bit difference", d0.max(), "fraction differing", float(np.mean(d0 > 0)))
+    assert d0.max() <= 1 and np.mean(d0 > 0) < 0.01
+
+
 def test_image_readers_against_an_independent_decoder(tmp_path):
     """apps/image_io.hpp (PNG, PNM, baseline JPEG readers of the CLI) through apps/imgconv, against PIL: the bundled city
     PNGs decode exactly, the reference's "car" JPEGs (finalProject/Project/car/[1-4].jpg, copied as data fixtures: baseline

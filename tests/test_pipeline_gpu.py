@@ -19,7 +19,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from tests.burst_compare import assert_parity, classify, psnr as _psnr, run_hip, run_oracle
+from tests.burst_compare import assert_parity, classify, flow_difference_report, psnr as _psnr, run_hip, run_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -64,11 +64,10 @@ def test_burst_matches_oracle(mono, fused, scale):
     h = _run_hip(cfg, frames)
     o = _run_oracle(cfg, frames)
     # reference-frame products
-    np.testing.assert_allclose(h["tracking"], o["tracking"], atol=1e-6)
-    # fused E1+E2 reads texels directly (<= 1e-6 relative blend difference), which the
-    # eigen-decomposition amplifies where the tensor is nearly isotropic: allow 0.1 % outliers
-    dk = np.abs(h["kparam"] - o["kparam"]) > (1e-4 + 2e-3 * np.abs(o["kparam"]))
-    assert np.mean(dk) < 1e-3
+    # reference-frame products are bit-identical: tracking image (A1 + luma + Gaussian, only + - * /) and the kernel
+    # parameters (E1-E3: the pipeline takes the bit-exact structure-tensor chain, csrc/pipeline.cpp)
+    assert np.array_equal(h["tracking"], o["tracking"])
+    assert np.array_equal(h["kparam"], o["kparam"], equal_nan=True)
     # last frame's flow (raw-pixel units) and robustness mask
     dflow = np.abs(h["flow"] - o["flow"])
     print(f"flow: max |d| {dflow.max():.2e} px, mean {dflow.mean():.2e}")
@@ -345,6 +344,24 @@ def test_frame_stream_matches_oracle_per_window(scale, radius, host):
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs at their own sizes
 # ---------------------------------------------------------------------------------------------------------------------
+def _flow_differences_are_localised(cfg, h, o, what):
+    """The HIP and the oracle flow differ by up to ~1e-3 px at these sizes (1e-5 px on small frames): assert WHERE.  Over
+    the well-conditioned, converged interior windows (tests/burst_compare.py::flow_difference_report: ~78 % of the pixels)
+    the difference stays <= 5e-4 px (measured: 2.5e-4 at 1080p, 3.0e-4 at 4K); every larger one sits in a window whose smaller singular value is in the lowest fifth
+    (noise x 1/sigma2, opticalFlow.cu:250-266), on the border rows, or where the flow itself is > 1 px off the frame's
+    shift (Lucas-Kanade not converged: wild border / low-texture flows)."""
+    for k in range(len(h["flows"])):
+        if k == cfg.reference:
+            continue
+        r = flow_difference_report(h["flows"][k], o["flows"][k], o["tracking"], cfg.lkHalfWindow, thr=5e-4)
+        print(f"[{what}] frame {k}: max |flow diff| {r['max_well']:.2e} px over the well-conditioned {r['well_fraction']:.0%}, "
+              f"{r['max_rest']:.2e} over the rest; {r['n_big']} px > 5e-4, {r['big_in_rest_fraction']:.0%} of them in the rest "
+              f"(sigma2 20th percentile {r['sigma2_p20']:.2e}, lkMinDet {cfg.lkMinDet:.1e})")
+        assert r["max_well"] <= 5e-4
+        assert r["n_big"] == 0 or r["big_in_rest_fraction"] == 1.0
+        assert r["max_rest"] <= 2e-2
+
+
 def _flow_locks(h, shifts, k, fs):
     """median flow of frame k in the centre region ~ -(true shift) in raw px"""
     f = h["flows"][k]
@@ -362,6 +379,7 @@ def test_config1_1080p_gray_x2_vs_oracle():
     o = run_oracle(cfg, frames)
     np.testing.assert_allclose(h["tracking"], o["tracking"], atol=1e-6)
     _flow_locks(h, shifts, 1, 1)
+    _flow_differences_are_localised(cfg, h, o, "configs[1]")
     assert_parity(classify(cfg, h, o), "configs[1] 1080p gray x2, 2-frame sample")
 
 
@@ -376,6 +394,7 @@ def test_config2_4k_rggb_x2_sample_vs_oracle():
     o = run_oracle(cfg, frames)
     for k in range(1, N):
         _flow_locks(h, shifts, k, 2)
+    _flow_differences_are_localised(cfg, h, o, "configs[2]")
     assert_parity(classify(cfg, h, o), "configs[2] 4K RGGB x2, 4-frame sample")
 
 
@@ -534,6 +553,54 @@ def test_joint_minimiser_burst_matches_oracle(ref_index):
     assert _psnr(p_out.cpu().numpy(), h["out"]) > 35.0
     pipe.close()
     plain.close()
+
+
+def test_joint_minimiser_rejects_an_inconsistent_measurement_like_the_oracle():
+    """Stage C's reject path end to end (checkForOutliers, ShiftMinimizerKernels.cu:81-139): a patch of ONE frame is replaced
+    by unrelated texture (an occlusion), so every pair that involves that frame measures an arbitrary shift in the tiles
+    under it -- inconsistent with the neighbouring pairs' sums, residual > 1 px^2 -- and the solve / reject loop drops those
+    rows.  The oracle's host-driven loop reports how many rows it dropped (> 0 here); the HIP burst (whole loop inside one
+    launch) must give the same tile shifts, or every frame's flow under the patch would differ: all frames go through the
+    flip-set classification with the continuous checks."""
+    import torch
+    from multi_frame_super_resolution_amd import capi
+    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, view_as_tensor
+    from multi_frame_super_resolution_amd.synth import make_burst
+    from oracle.pipeline import OraclePipeline
+    dev = torch.device("cuda:0")
+    W, H, N = 320, 256, 5
+    frames, shifts, gt = make_burst(W, H, N, scale=2, mono=False, seed=1234 + 9, max_shift=3.0)
+    rng = np.random.default_rng(99)
+    bad = frames[3].clone()
+    patch = torch.from_numpy(rng.integers(300, 3800, size=(96, 128), dtype=np.int64).astype(np.int16))
+    bad[80:176, 96:224] = patch
+    frames = list(frames)
+    frames[3] = bad
+    cfg = _cfg(W, H, N, 2, False, 1)
+    cfg.reference = 0
+    nf = [f.numpy().view(np.uint16) for f in frames]
+    op = OraclePipeline(cfg)
+    o_out, o_q = op.process_joint(nf)
+    print(f"oracle dropped {op.joint['dropped']} measurements (pairs {op.joint['pairs']})")
+    assert op.joint["dropped"] > 0, "the injected occlusion did not make any measurement inconsistent"
+    pipe = BurstPipeline(cfg, dev)
+    h_out, h_q = pipe.process_joint([f.to(dev) for f in frames])
+    torch.cuda.synchronize()
+    flows, masks = [], []
+    for k in range(N):
+        ft, mt = capi.Tex2D(), capi.Tex2D()
+        pipe.L.burst_debug_frame_views(pipe._h, N - 1 - k, ctypes.byref(ft), ctypes.byref(mt))
+        flows.append(view_as_tensor(ft, 2, dev).cpu().numpy())
+        masks.append(view_as_tensor(mt, 4, dev).cpu().numpy())
+    h = dict(out=h_out.cpu().numpy(), out16=h_q.cpu().numpy().view(np.uint16), img_out=pipe.img_out.cpu().numpy(),
+             tw=pipe.total_weights.cpu().numpy(), flows=flows, masks=masks)
+    o = dict(out=o_out, out16=o_q, img_out=op.img_out, tw=op.tw, flows=op.flows, masks=op.masks)
+    for k in range(1, N):
+        d = np.abs(flows[k] - op.flows[k])
+        print(f"frame {k}: max |flow diff| {d.max():.2e} px, fraction > 1e-3 px: {np.mean(d > 1e-3):.2e}")
+        assert np.mean(d > 1e-2) < 1e-3      # same tile shifts on both sides (a kept / dropped row moves a tile by >= 1 px)
+    assert_parity(classify(cfg, h, o), "joint burst with an occluded patch in frame 3", max_flip_fraction=0.1)
+    pipe.close()
 
 
 def test_frame_source_callback_equals_push_api():
