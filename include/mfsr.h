@@ -388,6 +388,23 @@ int mfsr_lucasKanadeIterationWarped(const mfsr_float2* shiftsIn, mfsr_float2* sh
                                     const float* movedImg, int pitchImg, const float* sumIn, const float* diffIn, float* sumOut,
                                     float* diffOut, int pitchSD, int width, int height, int halfWindowSize, float minDet,
                                     float outScale, mfsr_stream_t stream);
+/* The iteration of mfsr_lucasKanadeIterationWarped for 1 .. 4 frames against one reference in ONE launch (csrc/lk_fused.hip,
+ * k_lkSweep: one wavefront per 64 columns sweeping down a band of rows, vertical state in registers, horizontal window sums
+ * through whole-wave DPP shifts, no LDS).  Agrees with mfsr_lucasKanadeIterationWarped to fp32 rounding (another
+ * summation order of the row sums).  MFSR_E_UNSUPPORTED (nothing launched) for half windows outside 1..7 or width < 64:
+ * call the per-frame entry point then. */
+typedef struct {
+    const mfsr_float2* shiftsIn;
+    mfsr_float2* shiftsOut;
+    const float* movedImg;
+    const float* sumIn;
+    const float* diffIn;
+    float* sumOut;  /* NULL (with diffOut) on the last iteration */
+    float* diffOut;
+} mfsr_lk_frame;
+int mfsr_lucasKanadeSweepBatch(int nFrames, const mfsr_lk_frame* frames, const float* refImg, int pitchShift, int pitchImg,
+                               int pitchSD, int width, int height, int halfWindowSize, float minDet, float outScale,
+                               mfsr_stream_t stream);
 /* D1 (mfsr_CreateFlowFieldFromTiles; base != NULL: mfsr_CreateFlowFieldFromTilesBase) + the warp of every pixel under the flow
  * it writes: outImg and the first iteration's sumIn / diffIn in one launch (opticalFlow.cu:48 + :28) */
 int mfsr_CreateFlowFieldWarped(mfsr_float2* outImg, mfsr_tex2d texObjShiftXY, int imgWidth, int imgHeight, int imgPitch,

@@ -50,6 +50,13 @@ class PreAlign(ctypes.Structure):
                 ("tx", ctypes.c_int32), ("ty", ctypes.c_int32), ("level", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
 
 
+class LkFrame(ctypes.Structure):
+    """mfsr_lk_frame (include/mfsr.h): one frame of mfsr_lucasKanadeSweepBatch."""
+
+    _fields_ = [("shiftsIn", ctypes.c_void_p), ("shiftsOut", ctypes.c_void_p), ("movedImg", ctypes.c_void_p),
+                ("sumIn", ctypes.c_void_p), ("diffIn", ctypes.c_void_p), ("sumOut", ctypes.c_void_p), ("diffOut", ctypes.c_void_p)]
+
+
 class Config(ctypes.Structure):
     """mfsr_config (include/mfsr.h)."""
 

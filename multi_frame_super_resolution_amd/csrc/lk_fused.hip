@@ -29,6 +29,7 @@
 // Flow is double-buffered (shiftsIn -> shiftsOut): the halo of a tile reads
 // flow values owned by other workgroups, so an in-place update would race.
 #include <cstdlib>
+#include <cstring>
 #include "common.hpp"
 #include "lk_math.hpp"
 
@@ -430,4 +431,248 @@ extern "C" int mfsr_CreateFlowFieldWarped(mfsr_float2* outImg, mfsr_tex2d texObj
                            imgPitch, make_float2(baseShift.x, baseShift.y), baseRotation, base, refImg, movedImg, pitchImg, sumOut,
                            diffOut, pitchSD);
     return mfsr_launch_status("CreateFlowFieldWarped");
+}
+
+// ---- the same iteration as a register / DPP column sweep, for up to MFSR_LK_MAX_BATCH frames per launch -----------------------
+// k_lkIterationFused spends most of its ~430 VALU instructions per pixel around the arithmetic: a 32 x 16 tile stages
+// (32+10) x (16+10) samples (2.1x), forms the products on (32+6) x (16+6) (1.6x), moves everything through LDS with
+// index arithmetic for every element and crosses three barriers.  Here ONE WAVEFRONT owns 64 image columns and sweeps
+// down a band of rows, one image row per step, with no LDS and no barrier:
+//   * vertical state lives in registers of the lane that owns the column: the last five rows of (warped + ref) for the
+//     y derivative, the last 2h+1 rows of the five row-summed products (a ring the row loop is unrolled over, so the ring
+//     index is a compile-time register name);
+//   * horizontal neighbours come through the GFX9 whole-wave DPP shifts: Ix from wave_shl:1 / wave_shr:1 moves, the
+//     2h+1-wide row sums Horner-style -- acc = v + wave_shr:1(acc), 2h times: ONE v_add_f32_dpp per step, so lane l ends
+//     with the sum of lanes l-2h .. l, i.e. the window centred on column l - h, which is the pixel that lane then owns
+//     for the solve, the flow update and the warp that makes the next iteration's input (tools/ubench/dpp_wave_shift.hip
+//     checks the shifts on the hardware: 2.1 ns per wave-instruction, against 1.2 for a plain add);
+//   * of 64 lanes 64 - 2(h+2) produce a pixel (84 % at h = 3); a band of R rows reads R + 2(h+2) rows.
+// Same products, same column-sum order (top to bottom) and the same solve / update / warp code as k_lkIterationFused<PRE>;
+// the row sums add right to left instead of in the four-neighbour tree, so the flow agrees with it to fp32 rounding
+// (<= 1e-5 px on the tests), like every other summation order of this stage (header of this file).
+#define MFSR_LK_SWEEP_MAX_BATCH 4
+struct LkSweepFrame {
+    const float2* flowIn;
+    float2* flowOut;
+    const float* moved;
+    const float* sumIn;
+    const float* diffIn;
+    float* sumOut;   // nullptr on the last iteration
+    float* diffOut;
+};
+struct LkSweepBatch {
+    LkSweepFrame f[MFSR_LK_SWEEP_MAX_BATCH];
+};
+
+__device__ __forceinline__ float lk_wshr1(float v)  // lane l <- lane l-1 (lane 0 <- 0)
+{
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lk_wshl1(float v)  // lane l <- lane l+1 (lane 63 <- 0)
+{
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x130, 0xf, 0xf, true));
+}
+
+// the warp of lk_warp_sample in two phases, so that the gather a pixel issues after its flow update is consumed one row
+// later (the wave works on the next row meanwhile): same address arithmetic, same blend, same bits
+struct LkGather {
+    float t00, t10, t01, t11, a, b, rv, u, v;
+    bool interior;
+};
+__device__ __forceinline__ void lk_warp_issue(const float* __restrict__ movedImg, int pitchImg, int width, int height, int gx, int gy,
+                                              float2 f, float rv, LkGather& g)
+{
+    const float u = ((float)gx + 0.5f + f.x) / (float)width;   // opticalFlow.cu:38-39
+    const float v = ((float)gy + 0.5f + f.y) / (float)height;
+    const float xB = u * (float)width - 0.5f, yB = v * (float)height - 0.5f;
+    const float fx = floorf(xB), fy = floorf(yB);
+    const int ix = f2i(fx), iy = f2i(fy);
+    g.interior = u >= 0.0f && u < 1.0f && v >= 0.0f && v < 1.0f && (uint32_t)ix <= (uint32_t)(width - 2) &&
+                 (uint32_t)iy <= (uint32_t)(height - 2);
+    const int ixc = clampi(ix, 0, width - 2), iyc = clampi(iy, 0, height - 2);
+    const float* r0 = row_ptr(movedImg, pitchImg, iyc) + ixc;
+    const float* r1 = row_ptr(movedImg, pitchImg, iyc + 1) + ixc;
+    g.t00 = r0[0], g.t10 = r0[1], g.t01 = r1[0], g.t11 = r1[1];
+    g.a = xB - fx, g.b = yB - fy;
+    g.rv = rv, g.u = u, g.v = v;
+}
+__device__ __forceinline__ float lk_warp_finish(const float* __restrict__ movedImg, int pitchImg, int width, int height, const LkGather& g)
+{
+    float wv = lerp4(g.t00, g.t10, g.t01, g.t11, g.a, g.b);
+    if (__ballot(!g.interior) != 0) {
+        mfsr_tex2d texMoved;
+        texMoved.ptr = movedImg;
+        texMoved.pitch = pitchImg;
+        texMoved.width = width;
+        texMoved.height = height;
+        const float full = tex1<ADDR_MIRROR>(texMoved, g.u, g.v);
+        wv = g.interior ? wv : full;
+    }
+    return wv;
+}
+
+template <int HT>
+__global__ void __launch_bounds__(64)
+    k_lkSweep(LkSweepBatch batch, const float* __restrict__ refImg, int pitchShift, int pitchImg, int pitchSD, int width, int height,
+              float minDet, float outScale, int bandRows)
+{
+    constexpr int h = HT, HALO = HT + 2, WIN = 2 * HT + 1, VW = 64 - 2 * HALO;
+    const LkSweepFrame F = batch.f[blockIdx.z];
+    const int lane = threadIdx.x;
+    const int cx0 = blockIdx.x * VW, ry0 = blockIdx.y * bandRows;
+    const int colIn = cx0 - HALO + lane;              // the column this lane loads and differentiates
+    const int gxIn = lk_mirror_index(colIn, width);   // (-width <= colIn < 2 width: width >= 64 is required)
+    const int colOut = colIn - h;                     // the column whose window sum the Horner shifts leave in this lane
+    const bool outLane = lane >= 2 * h + 2 && lane <= 61 && colOut < width;
+    const int colOutC = min(max(colOut, 0), width - 1);
+    const bool ringCol = colOut < h || colOut >= width - h;
+    const int rows = min(bandRows, height - ry0);
+    const int T = rows + 2 * HALO;                    // input rows ry0 - HALO .. ry0 + rows - 1 + HALO
+
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;     // (warped + ref) of rows r-4 .. r
+    float d0 = 0, d1 = 0, d2 = 0;                     // (warped - ref) of rows r-2 .. r
+    float H[5][WIN];                                  // row sums of the five products, ring over rows
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+#pragma unroll
+        for (int j = 0; j < WIN; j++) H[k][j] = 0.0f;
+
+    auto load_row = [&](int t, float& sv, float& dv) {
+        const int gy = lk_mirror_index(ry0 - HALO + t, height);
+        sv = row_ptr(F.sumIn, pitchSD, gy)[gxIn];
+        dv = row_ptr(F.diffIn, pitchSD, gy)[gxIn];
+    };
+    // two rows in flight ahead of the one being worked on
+    float sA, dA, sB, dB;
+    load_row(0, sA, dA);
+    load_row(min(1, T - 1), sB, dB);
+    LkGather pend;            // the previous output row's warp, issued and not yet consumed
+    int pendY = -1;
+    auto finish_pending = [&]() {
+        if (pendY < 0) return;   // wave-uniform
+        const float wv = lk_warp_finish(F.moved, pitchImg, width, height, pend);
+        if (outLane) {
+            row_ptr(F.sumOut, pitchSD, pendY)[colOutC] = wv + pend.rv;
+            row_ptr(F.diffOut, pitchSD, pendY)[colOutC] = wv - pend.rv;
+        }
+    };
+
+    for (int t0 = 0; t0 < T; t0 += WIN) {
+#pragma unroll
+        for (int j = 0; j < WIN; j++) {
+            const int t = t0 + j;
+            if (t >= T) break;
+            // rotate the raw-row rings; fetch row t + 2
+            s0 = s1, s1 = s2, s2 = s3, s3 = s4, s4 = sA;
+            d0 = d1, d1 = d2, d2 = dA;
+            sA = sB, dA = dB;
+            load_row(min(t + 2, T - 1), sB, dB);
+            if (t < 4) continue;   // the derivative of row r - 2 needs rows r - 4 .. r
+            // this row's own flow and reference pixel: on their way while the sums are formed (every lane loads: clamped column)
+            const int y = ry0 + t - 2 * HALO;                  // the row whose window this step completes (if t >= 2 HALO)
+            const int yc = min(max(y, 0), height - 1);
+            float2 shift = row_ptr(F.flowIn, pitchShift, yc)[colOutC];
+            const float rvOwn = row_ptr(refImg, pitchImg, yc)[colOutC];
+            // products of image row r - 2 (opticalFlow.cu:116-131 on the sum image, as k_lkIterationFused step 2)
+            const float xp1 = lk_wshl1(s2), xp2 = lk_wshl1(xp1), xm1 = lk_wshr1(s2), xm2 = lk_wshr1(xm1);
+            float tx = xp2;
+            tx -= xp1 * 8.0f;
+            tx += xm1 * 8.0f;
+            tx -= xm2;
+            const float Ix = tx * (1.0f / 24.0f);
+            float ty = s4;
+            ty -= s3 * 8.0f;
+            ty += s1 * 8.0f;
+            ty -= s0;
+            const float Iy = ty * (1.0f / 24.0f);
+            const float It = d0;
+            float P[5] = {Ix * Ix, Ix * Iy, Iy * Iy, Ix * It, Iy * It};
+            // row sums: lane l <- lanes l - 2h .. l
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                float acc = P[k];
+#pragma unroll
+                for (int q = 0; q < 2 * HT; q++) acc = P[k] + lk_wshr1(acc);
+                H[k][j] = acc;
+            }
+            if (t < 2 * HALO) continue;   // the ring holds fewer than 2h+1 rows of this band yet
+            // column sums, top row first: the ring's oldest entry is slot j + 1
+            float V[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                float sum = 0;
+#pragma unroll
+                for (int d = 1; d <= WIN; d++) sum += H[k][(j + d) % WIN];
+                V[k] = sum;
+            }
+            if (!(ringCol || y < h || y >= height - h)) {
+                float inv[4];
+                if (lk_pinv(V[0], V[1], V[2], minDet, inv)) {
+                    float UV0 = inv[0] * V[3] + inv[1] * V[4];
+                    float UV1 = inv[2] * V[3] + inv[3] * V[4];
+                    UV0 = isnan(UV0) ? 0 : UV0;
+                    UV1 = isnan(UV1) ? 0 : UV1;
+                    shift.x += UV0;
+                    shift.y += UV1;
+                }
+            }
+            if (F.sumOut) {   // wave-uniform
+                finish_pending();   // the previous row's gather: issued one row ago
+                lk_warp_issue(F.moved, pitchImg, width, height, colOutC, y, shift, rvOwn, pend);
+                pendY = y;
+            }
+            shift.x *= outScale;
+            shift.y *= outScale;
+            if (outLane) row_ptr(F.flowOut, pitchShift, y)[colOutC] = shift;
+        }
+    }
+    if (F.sumOut) finish_pending();
+}
+
+extern "C" int mfsr_lucasKanadeSweepBatch(int nFrames, const mfsr_lk_frame* frames, const float* refImg, int pitchShift, int pitchImg,
+                                          int pitchSD, int width, int height, int halfWindowSize, float minDet, float outScale,
+                                          mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(frames && refImg && nFrames >= 1 && nFrames <= MFSR_LK_SWEEP_MAX_BATCH);
+    if (halfWindowSize < 1 || halfWindowSize > 7 || width < 64 || height < 2 * (halfWindowSize + 2)) return MFSR_E_UNSUPPORTED;
+    MFSR_REQUIRE((long long)pitchShift >= 8LL * width && (pitchShift & 7) == 0);
+    MFSR_REQUIRE((long long)pitchImg >= 4LL * width && (pitchImg & 3) == 0 && (long long)pitchSD >= 4LL * width && (pitchSD & 3) == 0);
+    LkSweepBatch b;
+    memset(&b, 0, sizeof(b));
+    for (int i = 0; i < nFrames; i++) {
+        const mfsr_lk_frame& f = frames[i];
+        MFSR_REQUIRE(f.shiftsIn && f.shiftsOut && f.shiftsIn != f.shiftsOut && f.movedImg && f.sumIn && f.diffIn);
+        MFSR_REQUIRE(((uintptr_t)f.shiftsIn & 7) == 0 && ((uintptr_t)f.shiftsOut & 7) == 0);
+        MFSR_REQUIRE((f.sumOut != nullptr) == (f.diffOut != nullptr) && f.sumOut != f.sumIn && f.diffOut != f.diffIn);
+        MFSR_REQUIRE(!f.sumOut || outScale == 1.0f);  // the flow a next iteration reads is in tracking pixels
+        b.f[i] = LkSweepFrame{(const float2*)f.shiftsIn, (float2*)f.shiftsOut, f.movedImg, f.sumIn, f.diffIn, f.sumOut, f.diffOut};
+    }
+    const int h = halfWindowSize, VW = 64 - 2 * (h + 2);
+    const int strips = mfsr_cdiv(width, VW);
+    // band height: enough wavefronts to fill 1024 SIMDs a few times over without paying too many halo rows
+    static const int forceBand = [] {
+        const char* e = getenv("MFSR_LK_BAND");
+        return e ? atoi(e) : 0;
+    }();
+    int band = (int)((long long)height * strips * nFrames / 4096);
+    band = band < 16 ? 16 : (band > 64 ? 64 : band);
+    band &= ~7;
+    if (forceBand >= 8) band = forceBand;
+    dim3 grid(strips, mfsr_cdiv(height, band), nFrames), block(64);
+#define LKS_CASE(HT)                                                                                                          \
+    case HT:                                                                                                                  \
+        hipLaunchKernelGGL(k_lkSweep<HT>, grid, block, 0, mfsr_s(stream), b, refImg, pitchShift, pitchImg, pitchSD, width,    \
+                           height, minDet, outScale, band);                                                                   \
+        break;
+    switch (h) {
+        LKS_CASE(1)
+        LKS_CASE(2)
+        LKS_CASE(3)
+        LKS_CASE(4)
+        LKS_CASE(5)
+        LKS_CASE(6)
+        LKS_CASE(7)
+    }
+#undef LKS_CASE
+    return mfsr_launch_status("lucasKanadeSweepBatch");
 }

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -73,6 +74,14 @@ struct Layout {
     // global pre-alignment (cfg.preAlign): search pyramids of the reference and the moved frame, workspace, result
     void *preRefPyr, *preMovPyr, *preWork;
     mfsr_prealign* preResult;
+    // frame-batched alignment (align_group): the moved frame's intermediates of frames 1 .. group-1 of a group (frame 0
+    // uses the members above); swapped in around the per-frame launches
+    struct AlignSet {
+        Img movHalf, movPyr[8], shifts[kMaxLevels], lkSum[2], lkDiff[2];
+        void* preMovPyr;
+        mfsr_prealign* preResult;
+    } sets[MFSR_MAX_FUSE_GROUP - 1];
+    int nSets;
     // host-frame bursts (cfg.uploadRing): device slots the library uploads into
     uint16_t* rawRing[kMaxUploadRing];
     uint16_t* refRaw[2];
@@ -216,10 +225,44 @@ void make_layout(const mfsr_config* c, char* base, Layout* L)
         L->preWork = b.take(mfsr_preAlign_workspace_bytes(c->preAlignMaxAngle));
         L->preResult = (mfsr_prealign*)b.take(sizeof(mfsr_prealign));
     }
+    L->nSets = 0;
+    if (c->fused && mfsr_burst_group_size(c) > 1) {
+        L->nSets = mfsr_burst_group_size(c) - 1;
+        for (int q = 0; q < L->nSets; q++) {
+            Layout::AlignSet& S = L->sets[q];
+            S.movHalf = b.image(L->hw, L->hh, 12);
+            for (int i = 0; i < nl; i++) S.movPyr[i] = b.image(L->tw >> i, L->th >> i, 4);
+            for (int l = 0; l < c->levels; l++) S.shifts[l] = b.image(L->tcx[l], L->tcy[l], 8);
+            for (int i = 0; i < 2; i++) {
+                S.lkSum[i] = b.image(L->tw, L->th, 4);
+                S.lkDiff[i] = b.image(L->tw, L->th, 4);
+            }
+            S.preMovPyr = nullptr;
+            S.preResult = nullptr;
+            if (c->preAlign) {
+                S.preMovPyr = b.take(mfsr_preAlign_pyramid_bytes(L->tw, L->th));
+                S.preResult = (mfsr_prealign*)b.take(sizeof(mfsr_prealign));
+            }
+        }
+    }
     for (int i = 0; i < c->uploadRing; i++) L->rawRing[i] = (uint16_t*)b.take((size_t)L->W * L->H * 2);
     if (c->uploadRing > 0)
         for (int i = 0; i < 2; i++) L->refRaw[i] = (uint16_t*)b.take((size_t)L->W * L->H * 2);
     L->total = align_up(b.off, 256);
+}
+
+// exchange the moved-frame intermediates named by the Layout members with those of an align set
+void swap_set(Layout& L, Layout::AlignSet& S)
+{
+    std::swap(L.movHalf, S.movHalf);
+    for (int i = 0; i < 8; i++) std::swap(L.movPyr[i], S.movPyr[i]);
+    for (int l = 0; l < kMaxLevels; l++) std::swap(L.shifts[l], S.shifts[l]);
+    for (int i = 0; i < 2; i++) {
+        std::swap(L.lkSum[i], S.lkSum[i]);
+        std::swap(L.lkDiff[i], S.lkDiff[i]);
+    }
+    std::swap(L.preMovPyr, S.preMovPyr);
+    std::swap(L.preResult, S.preResult);
 }
 
 mfsr_tex2d as_tex(const Img& im)
@@ -254,6 +297,8 @@ struct mfsr_burst {
         const uint16_t* raw[MFSR_MAX_FUSE_GROUP];
         Img* flow[MFSR_MAX_FUSE_GROUP];
         Img* mask[MFSR_MAX_FUSE_GROUP];
+        bool deferred[MFSR_MAX_FUSE_GROUP];  // not aligned yet: align_deferred aligns the waiting frames as one batch
+        int isRef[MFSR_MAX_FUSE_GROUP];
         mfsr_float3 *imgOut, *totalWeights;
     } pend;
     int group;  // frames per warp+fuse launch (mfsr_burst_group_size)
@@ -678,9 +723,12 @@ static int upload_slot_of(const mfsr_burst* b, const uint16_t* raw)
     return -1;
 }
 
+static int align_deferred(mfsr_burst* b, mfsr_stream_t stream);
+
 // G: the waiting group (b->pend, 1 .. MFSR_MAX_FUSE_GROUP aligned frames) onto its accumulators (timed with HIP events on request)
 static int accumulate_pending(mfsr_burst* b, mfsr_stream_t callerStream)
 {
+    TRY(align_deferred(b, callerStream));  // frames of the group that were waiting for their batch
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
     const mfsr_burst::Pending p = b->pend;
@@ -776,24 +824,43 @@ static int flush_pending(mfsr_burst* b, mfsr_stream_t stream, bool materializeFr
 }
 
 // A1 + (I) + B + D + F of one frame into ring slot `slot`: *flowOut / *maskOut name the buffers that hold the result
+// phases: ALIGN_PRE = everything up to the flow field (+ first warp), ALIGN_LK = the Lucas-Kanade iterations, ALIGN_POST = the
+// robustness mask.  align_group runs PRE and POST frame by frame and the iterations of a whole group in one launch each.
+enum { ALIGN_PRE = 1, ALIGN_LK = 2, ALIGN_POST = 4, ALIGN_ALL = 7 };
+static bool lk_warped_path(const mfsr_burst* b)
+{
+    // fused LK: the warped moved image travels from launch to launch (every pixel warped once per iteration, by the
+    // thread that has just updated its flow) instead of being re-gathered for every tile halo; MFSR_LK_WARPED=0: A/B
+    static const bool lkWarped = [] {
+        const char* e = getenv("MFSR_LK_WARPED");
+        return !(e && e[0] == '0');
+    }();
+    const mfsr_config& c = b->cfg;
+    return c.fused && lkWarped && c.lkIterations > 0 && b->L.tw >= 64 && b->L.th >= 32;
+}
+
 static int align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, int slot, Img** flowOut, Img** maskOut,
-                       mfsr_stream_t stream)
+                       mfsr_stream_t stream, int phases = ALIGN_ALL)
 {
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
     // the slot's buffers are free once the fuse that read them last has run
-    if (b->fuseStream && b->fusedOutstanding[slot]) {
+    if ((phases & ALIGN_PRE) && b->fuseStream && b->fusedOutstanding[slot]) {
         MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evFused[slot], 0));
         b->fusedOutstanding[slot] = false;
     }
     Img* flow = &L.flowBuf[2 * slot];
     Img* other = &L.flowBuf[2 * slot + 1];
     Img* mask = &L.maskBuf[slot];
+    const bool warped = lk_warped_path(b);
     if (isReference) {
         // identity flow, certainty 1
-        MFSR_HIP_TRY(hipMemsetAsync(flow->ptr, 0, (size_t)flow->pitch * flow->h, mfsr_s(stream)));
-        TRY(mfsr_fill_f32((float*)mask->ptr, (size_t)mask->pitch / 4 * mask->h, 1.0f, stream));
+        if (phases & ALIGN_PRE) {
+            MFSR_HIP_TRY(hipMemsetAsync(flow->ptr, 0, (size_t)flow->pitch * flow->h, mfsr_s(stream)));
+            TRY(mfsr_fill_f32((float*)mask->ptr, (size_t)mask->pitch / 4 * mask->h, 1.0f, stream));
+        }
     } else {
+      if (phases & ALIGN_PRE) {
         if (!b->movPrepared) TRY(prepare_frame(b, raw, L.movHalf, L.movPyr, stream));
         // I: global pre-alignment (base shift + rotation of this frame against the reference), kept in device memory
         mfsr_prealign hostBase;
@@ -813,13 +880,6 @@ static int align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, int 
         const int last = c.levels - 1;
         const Img& tileShifts = b->givenShifts ? *b->givenShifts : L.shifts[last];
         const mfsr_float2 zero2 = {0.0f, 0.0f};
-        // fused LK: the warped moved image travels from launch to launch (every pixel warped once per iteration, by the
-        // thread that has just updated its flow) instead of being re-gathered for every tile halo; MFSR_LK_WARPED=0: A/B
-        static const bool lkWarped = [] {
-            const char* e = getenv("MFSR_LK_WARPED");
-            return !(e && e[0] == '0');
-        }();
-        const bool warped = c.fused && lkWarped && c.lkIterations > 0 && L.tw >= 64 && L.th >= 32;
         if (warped) {
             TRY(mfsr_CreateFlowFieldWarped((mfsr_float2*)flow->ptr, as_tex(tileShifts), L.tw, L.th, flow->pitch, zero2, 0.0f,
                                            c.preAlign ? L.preResult : nullptr, (const float*)L.refPyr[0].ptr,
@@ -839,10 +899,33 @@ static int align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, int 
             TRY(mfsr_CreateFlowFieldFromTiles((mfsr_float2*)flow->ptr, as_tex(tileShifts), c.tileSize[last], L.tcx[last],
                                               L.tcy[last], L.tw, L.th, flow->pitch, base, rot, stream));
         }
+      }
+      if (phases & ALIGN_LK) {
         for (int it = 0; it < c.lkIterations; it++) {
             if (warped) {
                 const bool lastIt = it == c.lkIterations - 1;
                 const int in = it & 1, out = in ^ 1;
+                // the sweep kernel wherever it applies, also for a single frame: the frame-by-frame paths (frame streams,
+                // joint mode, mfsr_burst_align_frame of the multi-GPU layer, groups of one) then give the very bits of the
+                // frame-batched burst -- its result does not depend on how many frames share a launch
+                mfsr_lk_frame one;
+                one.shiftsIn = (const mfsr_float2*)flow->ptr;
+                one.shiftsOut = (mfsr_float2*)other->ptr;
+                one.movedImg = (const float*)L.movPyr[0].ptr;
+                one.sumIn = (const float*)L.lkSum[in].ptr;
+                one.diffIn = (const float*)L.lkDiff[in].ptr;
+                one.sumOut = lastIt ? nullptr : (float*)L.lkSum[out].ptr;
+                one.diffOut = lastIt ? nullptr : (float*)L.lkDiff[out].ptr;
+                const int rcs = mfsr_lucasKanadeSweepBatch(1, &one, (const float*)L.refPyr[0].ptr, flow->pitch, L.refPyr[0].pitch,
+                                                           L.lkSum[0].pitch, L.tw, L.th, c.lkHalfWindow, c.lkMinDet,
+                                                           lastIt ? (float)L.flowScale : 1.0f, stream);
+                if (rcs != MFSR_E_UNSUPPORTED) {
+                    if (rcs) return rcs;
+                    Img* t = flow;
+                    flow = other;
+                    other = t;
+                    continue;
+                }
                 TRY(mfsr_lucasKanadeIterationWarped((const mfsr_float2*)flow->ptr, (mfsr_float2*)other->ptr, flow->pitch,
                                                     (const float*)L.refPyr[0].ptr, (const float*)L.movPyr[0].ptr, L.refPyr[0].pitch,
                                                     (const float*)L.lkSum[in].ptr, (const float*)L.lkDiff[in].ptr,
@@ -875,6 +958,13 @@ static int align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, int 
         }
         if (L.flowScale != 1 && !(c.fused && c.lkIterations > 0))  // the fused LK scales on its last iteration
             TRY(mfsr_scaleFlow((mfsr_float2*)flow->ptr, flow->pitch, L.tw, L.th, (float)L.flowScale, stream));
+      } else if (c.fused && (c.lkIterations & 1)) {
+        // the iterations ran elsewhere (align_group): an odd number of them leaves the flow in the slot's other buffer
+        Img* t = flow;
+        flow = other;
+        other = t;
+      }
+      if (phases & ALIGN_POST) {
         // F: robustness mask (the 1-px ring is never written by the kernel -> zero it)
         if (c.fused) {
             TRY(mfsr_robustnessMaskFused((const mfsr_float3*)L.refHalf.ptr, (const mfsr_float3*)L.movHalf.ptr,
@@ -886,10 +976,97 @@ static int align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, int 
                                            (mfsr_float4*)mask->ptr, as_tex(*flow), L.hw, L.hh, L.refHalf.pitch, mask->pitch,
                                            c.alpha, c.beta, c.thresholdM, stream));
         }
+      }
     }
     *flowOut = flow;
     *maskOut = mask;
     b->slotFlow[slot] = flow;  // mfsr_burst_debug_frame_views
+    return MFSR_OK;
+}
+
+// Frame-batched alignment.  The frames of a fuse group are independent given the reference's products, and one frame's
+// alignment is a chain of small launches (prepare, two tracker levels, flow field, lkIterations x Lucas-Kanade, robustness:
+// 8 at the defaults, 10..30 us each at 4K) -- so add_frame only REGISTERS a frame while its group fills, and the group is
+// aligned as one batch when it is complete (or on flush / finish): the per-frame stages frame after frame into per-frame
+// intermediates (Layout::sets), every Lucas-Kanade iteration of all frames in ONE launch (mfsr_lucasKanadeSweepBatch).
+// Same kernels' arithmetic per frame as the frame-by-frame path except the sweep kernel's row-sum order (fp32 rounding of
+// the flow).  Frames whose intermediates the caller supplies (frame streams, the joint mode) take the frame-by-frame path.
+static bool can_defer_alignment(const mfsr_burst* b)
+{
+    static const bool on = [] {
+        const char* e = getenv("MFSR_ALIGN_BATCH");
+        return !(e && e[0] == '0');
+    }();
+    const mfsr_config& c = b->cfg;
+    return on && b->group > 1 && b->L.nSets >= b->group - 1 && lk_warped_path(b) && c.lkHalfWindow >= 1 && c.lkHalfWindow <= 7 &&
+           !b->movPrepared && !b->givenShifts;
+}
+
+static int align_deferred(mfsr_burst* b, mfsr_stream_t stream)
+{
+    const mfsr_config& c = b->cfg;
+    Layout& L = b->L;
+    int idx[MFSR_MAX_FUSE_GROUP], n = 0;
+    for (int i = 0; i < b->pend.n; i++)
+        if (b->pend.deferred[i]) idx[n++] = i;
+    if (n == 0) return MFSR_OK;
+    // per-frame stages up to the flow field + first warp; frame q > 0 of the batch works in align set q - 1
+    for (int q = 0; q < n; q++) {
+        const int i = idx[q];
+        if (q > 0) swap_set(L, L.sets[q - 1]);
+        Img *flow = nullptr, *mask = nullptr;
+        const int rc = align_frame(b, b->pend.raw[i], b->pend.isRef[i], b->pend.slot[i], &flow, &mask, stream, ALIGN_PRE);
+        if (q > 0) swap_set(L, L.sets[q - 1]);
+        if (rc) return rc;
+    }
+    // every Lucas-Kanade iteration of the batch in one launch
+    bool batched = true;
+    for (int it = 0; it < c.lkIterations && batched; it++) {
+        mfsr_lk_frame fr[MFSR_MAX_FUSE_GROUP];
+        int m = 0;
+        const bool lastIt = it == c.lkIterations - 1;
+        const int in = it & 1, out = in ^ 1;
+        for (int q = 0; q < n; q++) {
+            const int i = idx[q];
+            if (b->pend.isRef[i]) continue;
+            const int slot = b->pend.slot[i];
+            const Img* sum = q == 0 ? L.lkSum : L.sets[q - 1].lkSum;
+            const Img* diff = q == 0 ? L.lkDiff : L.sets[q - 1].lkDiff;
+            const Img& mov = q == 0 ? L.movPyr[0] : L.sets[q - 1].movPyr[0];
+            fr[m].shiftsIn = (const mfsr_float2*)L.flowBuf[2 * slot + in].ptr;
+            fr[m].shiftsOut = (mfsr_float2*)L.flowBuf[2 * slot + out].ptr;
+            fr[m].movedImg = (const float*)mov.ptr;
+            fr[m].sumIn = (const float*)sum[in].ptr;
+            fr[m].diffIn = (const float*)diff[in].ptr;
+            fr[m].sumOut = lastIt ? nullptr : (float*)sum[out].ptr;
+            fr[m].diffOut = lastIt ? nullptr : (float*)diff[out].ptr;
+            m++;
+        }
+        if (m == 0) break;
+        const int rc = mfsr_lucasKanadeSweepBatch(m, fr, (const float*)L.refPyr[0].ptr, L.flowBuf[0].pitch, L.refPyr[0].pitch,
+                                                  L.lkSum[0].pitch, L.tw, L.th, c.lkHalfWindow, c.lkMinDet,
+                                                  lastIt ? (float)L.flowScale : 1.0f, stream);
+        if (rc == MFSR_E_UNSUPPORTED && it == 0)
+            batched = false;  // (cannot happen after can_defer_alignment; kept as a safe fallback)
+        else if (rc)
+            return rc;
+    }
+    // robustness masks (and, without the batch kernel, the iterations frame by frame)
+    for (int q = 0; q < n; q++) {
+        const int i = idx[q];
+        if (q > 0) swap_set(L, L.sets[q - 1]);
+        Img *flow = nullptr, *mask = nullptr;
+        const int rc = align_frame(b, b->pend.raw[i], b->pend.isRef[i], b->pend.slot[i], &flow, &mask, stream,
+                                   batched ? ALIGN_POST : (ALIGN_LK | ALIGN_POST));
+        if (q > 0) swap_set(L, L.sets[q - 1]);
+        if (rc) return rc;
+        b->pend.flow[i] = flow;
+        b->pend.mask[i] = mask;
+        b->pend.deferred[i] = false;
+        b->flowCur = flow;
+        b->maskCur = mask;
+        if (b->fuseStream) MFSR_HIP_TRY(hipEventRecord(b->evAligned[b->pend.slot[i]], mfsr_s(stream)));
+    }
     return MFSR_OK;
 }
 
@@ -901,19 +1078,25 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
     MFSR_REQUIRE(!b->refStale);  // after mfsr_burst_process_joint: call mfsr_burst_set_reference first
     const mfsr_config& c = b->cfg;
     TRY(mfsr_set_cfa_pattern(c.cfa));
+    // G: accumulate onto the HR grid -- alone, or together with the frames that were waiting for the rest of their group
+    if (b->pend.n && (b->pend.imgOut != imgOut || b->pend.totalWeights != totalWeights)) TRY(flush_pending(b, stream));
     const int slot = b->frameCounter++ % kRing;
     Img *flow = nullptr, *mask = nullptr;
-    TRY(align_frame(b, raw, isReference, slot, &flow, &mask, stream));
-    b->flowCur = flow;
-    b->maskCur = mask;
-    if (b->fuseStream) MFSR_HIP_TRY(hipEventRecord(b->evAligned[slot], mfsr_s(stream)));
-    // G: accumulate onto the HR grid -- alone, or together with the frame that was waiting for a partner
-    if (b->pend.n && (b->pend.imgOut != imgOut || b->pend.totalWeights != totalWeights)) TRY(flush_pending(b, stream));
+    const bool defer = can_defer_alignment(b);
+    if (!defer) {
+        TRY(align_deferred(b, stream));  // keep the alignment in frame order on the stream
+        TRY(align_frame(b, raw, isReference, slot, &flow, &mask, stream));
+        b->flowCur = flow;
+        b->maskCur = mask;
+        if (b->fuseStream) MFSR_HIP_TRY(hipEventRecord(b->evAligned[slot], mfsr_s(stream)));
+    }
     const int i = b->pend.n++;
     b->pend.slot[i] = slot;
     b->pend.raw[i] = raw;
     b->pend.flow[i] = flow;
     b->pend.mask[i] = mask;
+    b->pend.deferred[i] = defer;
+    b->pend.isRef[i] = isReference;
     b->pend.imgOut = imgOut;
     b->pend.totalWeights = totalWeights;
     if (b->pend.n < b->group) return MFSR_OK;  // the group is fused when its last frame arrives (or on flush / finish)

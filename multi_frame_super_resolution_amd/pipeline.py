@@ -216,6 +216,13 @@ class BurstPipeline:
         self.L.burst_debug_views(self._h, *[ctypes.byref(x) for x in t])
         return t
 
+    def frame_views(self, frames_back: int):
+        """(flow, mask) descriptors of the frame aligned ``frames_back`` frames before the last one (mfsr_burst_debug_frame_views).
+        With frame-batched alignment a frame is aligned when its group is complete (or on flush / finish), not by add_frame."""
+        f, m = capi.Tex2D(), capi.Tex2D()
+        self.L.burst_debug_frame_views(self._h, int(frames_back), ctypes.byref(f), ctypes.byref(m))
+        return f, m
+
     def _check_raw(self, raw: torch.Tensor):
         if raw.device != self.device or raw.dtype not in (torch.int16, torch.uint16) or not raw.is_contiguous():
             raise ValueError("raw frame must be a contiguous 16-bit tensor on the pipeline's device")

@@ -14,16 +14,28 @@ def run_hip(cfg, frames, device="cuda:0", per_frame=True):
     dev = torch.device(device)
     pipe = BurstPipeline(cfg, dev)
     dframes = [f.to(dev) for f in frames]
-    flows, masks = [], []
+    n = len(dframes)
+    flows, masks = [None] * n, [None] * n
     pipe.begin_burst()
     ref = cfg.reference
     pipe.set_reference(dframes[ref])
-    for k in range(len(dframes)):
+    group = max(pipe.group_size(), 1)
+    unread = []
+    for k in range(n):
         pipe.add_frame(dframes[k], k == ref)
-        if per_frame or k == len(dframes) - 1:
-            flow_t, mask_t, _, _ = pipe.debug_views()
-            flows.append(view_as_tensor(flow_t, 2, dev).cpu().numpy())
-            masks.append(view_as_tensor(mask_t, 4, dev).cpu().numpy())
+        unread.append(k)
+        # a frame is aligned when its fuse group is complete (frame-batched alignment) or on flush -- which finish() does
+        # for the last, partial group anyway, so flushing there changes nothing of the burst
+        if (k + 1) % group == 0 or k == n - 1:
+            if k == n - 1:
+                pipe.flush()
+            for j in (unread if per_frame else unread[-1:]):
+                flow_t, mask_t = pipe.frame_views(k - j)
+                flows[j] = view_as_tensor(flow_t, 2, dev).cpu().numpy()
+                masks[j] = view_as_tensor(mask_t, 4, dev).cpu().numpy()
+            unread = []
+    if not per_frame:
+        flows, masks = [flows[-1]], [masks[-1]]
     out, out16 = pipe.finish()
     torch.cuda.synchronize()
     _, _, kp_t, trk_t = pipe.debug_views()

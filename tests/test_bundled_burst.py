@@ -117,6 +117,7 @@ def test_hip_matches_oracle_on_the_bundled_burst():
     io, tw = np.zeros((2 * H, 2 * W, 3), np.float32), np.zeros((2 * H, 2 * W, 3), np.float32)
     for k in range(1, 5):
         pipe.add_frame(frames[k].to(dev), False)
+        pipe.flush()     # frame-batched alignment: a frame is aligned when its group is complete or on flush
         op.add_frame(raws[k], False, io, tw)
         pa = capi.PreAlign()
         pipe.L.burst_prealign_result(pipe._h, ctypes.byref(pa), None)
