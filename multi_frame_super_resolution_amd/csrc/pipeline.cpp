@@ -320,6 +320,9 @@ struct mfsr_burst {
     hipStream_t downStream;                 // D2H of the finished image (mfsr_burst_finish_host), concurrent with the uploads
     hipEvent_t evFinished, evDown;          // finish kernel done (compute stream) / D2H done (down stream)
     bool downRecorded;
+    hipEvent_t evBand[16];                  // host bursts: band i of the output image finished (mfsr_burst_finish_host)
+    int framesSinceRef;                     // frames added since the last set_reference
+    bool holdLastGroup;                     // host bursts: the group the burst's last frame completes waits for finish_host
     hipEvent_t evUp[kMaxUploadRing + 2];    // upload of the slot complete (copy stream); [ring..ring+1] = reference slots
     hipEvent_t evFree[kMaxUploadRing + 2];  // last consumer of the slot enqueued (compute / fuse stream)
     bool freeRecorded[kMaxUploadRing + 2];
@@ -474,6 +477,9 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     b->evFinished = b->evDown = nullptr;
     b->downRecorded = false;
     b->upCounter = b->refCounter = 0;
+    for (int i = 0; i < 16; i++) b->evBand[i] = nullptr;
+    b->framesSinceRef = 0;
+    b->holdLastGroup = false;
     b->refHost = b->refDev = nullptr;
     for (int i = 0; i < kMaxUploadRing + 2; i++) {
         b->evUp[i] = b->evFree[i] = nullptr;
@@ -516,6 +522,8 @@ extern "C" void mfsr_burst_destroy(mfsr_burst* b)
     if (b->downStream) (void)hipStreamSynchronize(b->downStream);
     if (b->evFinished) (void)hipEventDestroy(b->evFinished);
     if (b->evDown) (void)hipEventDestroy(b->evDown);
+    for (int i = 0; i < 16; i++)
+        if (b->evBand[i]) (void)hipEventDestroy(b->evBand[i]);
     if (b->downStream) (void)hipStreamDestroy(b->downStream);
     for (int i = 0; i < kMaxUploadRing + 2; i++) {
         if (b->evUp[i]) (void)hipEventDestroy(b->evUp[i]);
@@ -645,6 +653,7 @@ extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, m
     }
     b->haveRef = true;
     b->refStale = false;
+    b->framesSinceRef = 0;
     return MFSR_OK;
 }
 
@@ -998,8 +1007,16 @@ static bool can_defer_alignment(const mfsr_burst* b)
         return !(e && e[0] == '0');
     }();
     const mfsr_config& c = b->cfg;
+    // (host bursts: frames are aligned one by one as they come off the PCIe link -- waiting for a whole group would leave
+    // the GPU idle during the first uploads and would put the whole last group's alignment between the last upload and
+    // the first byte of the download; MFSR_HOST_DEFER=1 batches the groups after the first anyway)
+    static const bool hostDefer = [] {
+        const char* e = getenv("MFSR_HOST_DEFER");
+        return e && e[0] == '1';
+    }();
+    const bool hostImmediate = b->holdLastGroup && (b->framesSinceRef < b->group || !hostDefer);
     return on && b->group > 1 && b->L.nSets >= b->group - 1 && lk_warped_path(b) && c.lkHalfWindow >= 1 && c.lkHalfWindow <= 7 &&
-           !b->movPrepared && !b->givenShifts;
+           !b->movPrepared && !b->givenShifts && !hostImmediate;
 }
 
 static int align_deferred(mfsr_burst* b, mfsr_stream_t stream)
@@ -1099,7 +1116,11 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
     b->pend.isRef[i] = isReference;
     b->pend.imgOut = imgOut;
     b->pend.totalWeights = totalWeights;
+    b->framesSinceRef++;
     if (b->pend.n < b->group) return MFSR_OK;  // the group is fused when its last frame arrives (or on flush / finish)
+    // host bursts: the group that the burst's last frame completes is fused band by band by mfsr_burst_finish_host, so that
+    // finished bands of the image leave for the host while the later ones are still being fused
+    if (b->holdLastGroup && b->framesSinceRef >= c.frames) return MFSR_OK;
     return accumulate_pending(b, stream);
 }
 
@@ -1317,6 +1338,11 @@ extern "C" int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw,
 {
     MFSR_REQUIRE(b && hostRaw && imgOut && totalWeights);
     MFSR_REQUIRE(b->copyStream != nullptr);
+    static const bool banded = [] {
+        const char* e = getenv("MFSR_HOST_BANDS");
+        return !(e && e[0] == '0');
+    }();
+    b->holdLastGroup = banded;
     if (isReference && hostRaw == b->refHost && b->refDev)
         return mfsr_burst_add_frame(b, b->refDev, 1, imgOut, totalWeights, stream);
     const int us = b->upCounter++ % b->cfg.uploadRing;
@@ -1330,18 +1356,100 @@ extern "C" int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw,
     return mfsr_burst_add_frame(b, b->L.rawRing[us], isReference, imgOut, totalWeights, stream);
 }
 
+// finish + download in row bands.  What is still waiting to be fused (normally the burst's last group, held back by
+// add_frame) is fused band by band, each band is normalised as soon as it is complete, and its u16 rows start their way to
+// the host while the next band is being fused: the 6 B/px download overlaps the tail of the compute instead of following
+// it.  Row-window fuse / finish are bit-identical to the whole-frame launches (the multi-GPU stripes rest on the same).
+// The download is a 2-D copy: the runtime hands those to an SDMA engine, whereas hipMemcpyAsync(DeviceToHost) is carried out
+// by a blit KERNEL on this ROCm (no memory-copy record in a rocprofv3 trace, a __amd_rocclr_copyBuffer dispatch instead) whose
+// PCIe-bound stores slow a warp+fuse launch running beside it 4-5x (profiles/r03_e2e_timeline_blit.txt) -- as did a
+// hand-written copy kernel with a 32-workgroup grid: it is the store path that clogs, not the wave slots.
+// (One more stream in the context -- a second upload stream was tried -- maps two streams onto one hardware queue and costs
+// 4 ms per burst: the context stays at its four streams.)
 extern "C" int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights,
                                       uint16_t* out16Dev, uint16_t* out16Host, mfsr_stream_t stream)
 {
-    MFSR_REQUIRE(b && out16Dev && out16Host);
+    MFSR_REQUIRE(b && imgOut && totalWeights && out16Dev && out16Host);
     MFSR_REQUIRE(b->downStream != nullptr);  // cfg.uploadRing > 0
+    MFSR_REQUIRE(b->haveRef);
+    const mfsr_config& c = b->cfg;
+    Layout& L = b->L;
     // the previous image may still be on its way to the host out of out16Dev
     if (b->downRecorded) MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evDown, 0));
-    TRY(mfsr_burst_finish(b, imgOut, totalWeights, nullptr, out16Dev, stream));
-    // D2H on a stream of its own: the next burst's uploads and kernels run while this image goes out (full-duplex PCIe)
-    MFSR_HIP_TRY(hipEventRecord(b->evFinished, mfsr_s(stream)));
-    MFSR_HIP_TRY(hipStreamWaitEvent(b->downStream, b->evFinished, 0));
-    MFSR_HIP_TRY(hipMemcpyAsync(out16Host, out16Dev, (size_t)b->L.hrW * b->L.hrH * 6, hipMemcpyDeviceToHost, b->downStream));
+    static const int nBandsEnv = [] {
+        const char* e = getenv("MFSR_HOST_BANDS");
+        return e ? atoi(e) : 8;
+    }();
+    int nBands = nBandsEnv < 1 ? 1 : (nBandsEnv > 16 ? 16 : nBandsEnv);
+    const bool heldGroup = b->pend.n > 0 && b->pend.imgOut == imgOut && b->pend.totalWeights == totalWeights && c.fused;
+    if (!heldGroup) TRY(flush_pending(b, stream));  // (another accumulator pair, or the unfused chain: nothing to pipeline)
+    const size_t rowBytes = (size_t)L.hrW * 6;
+    if (nBands == 1 && !heldGroup) {
+        TRY(mfsr_burst_finish(b, imgOut, totalWeights, nullptr, out16Dev, stream));
+        MFSR_HIP_TRY(hipEventRecord(b->evFinished, mfsr_s(stream)));
+        MFSR_HIP_TRY(hipStreamWaitEvent(b->downStream, b->evFinished, 0));
+        MFSR_HIP_TRY(hipMemcpy2DAsync(out16Host, rowBytes, out16Dev, rowBytes, rowBytes, (size_t)L.hrH, hipMemcpyDeviceToHost,
+                                      b->downStream));
+        MFSR_HIP_TRY(hipEventRecord(b->evDown, b->downStream));
+        b->downRecorded = true;
+        return MFSR_OK;
+    }
+    mfsr_burst::Pending p = b->pend;
+    int freshNow = 0;
+    if (heldGroup) {
+        TRY(align_deferred(b, stream));
+        p = b->pend;
+        b->pend.n = 0;
+        TRY(join_fuse(b, stream));  // the earlier groups' launches ran on the burst's own stream
+        freshNow = b->fresh.has && b->fresh.imgOut == imgOut && b->fresh.totalWeights == totalWeights;
+        if (b->fresh.has && !freshNow) {
+            const size_t bytes = (size_t)12 * L.hrW * L.hrH;
+            MFSR_HIP_TRY(hipMemsetAsync(b->fresh.imgOut, 0, bytes, mfsr_s(stream)));
+            MFSR_HIP_TRY(hipMemsetAsync(b->fresh.totalWeights, 0, bytes, mfsr_s(stream)));
+        }
+        b->fresh.has = false;
+    }
+    const mfsr_float3 white = {c.white[0], c.white[1], c.white[2]};
+    const mfsr_float3 black = {c.black[0], c.black[1], c.black[2]};
+    const int tileRows = (L.hrH + 15) / 16;
+    if (nBands > tileRows) nBands = tileRows;
+    for (int i = 0; i < nBands; i++) {
+        const int r0 = (int)((long long)tileRows * i / nBands) * 16;
+        int r1 = (int)((long long)tileRows * (i + 1) / nBands) * 16;
+        if (r1 > L.hrH || i == nBands - 1) r1 = L.hrH;
+        if (r1 <= r0) continue;
+        if (heldGroup) {
+            const mfsr_float4* masks[MFSR_MAX_FUSE_GROUP];
+            mfsr_tex2d flows[MFSR_MAX_FUSE_GROUP];
+            for (int k = 0; k < p.n; k++) {
+                masks[k] = (const mfsr_float4*)p.mask[k]->ptr;
+                flows[k] = as_tex(*p.flow[k]);
+            }
+            TRY(mfsr_accumulateSuperResFullRows(p.n, p.raw, const_cast<mfsr_float3*>(imgOut), const_cast<mfsr_float3*>(totalWeights),
+                                                masks, as_tex(L.kparam4), flows, white, black, L.W, L.H, c.scale, 12 * L.hrW,
+                                                p.mask[0]->pitch, freshNow, r0, r1, stream));
+        }
+        const size_t off = (size_t)r0 * 12 * L.hrW;
+        TRY(mfsr_finishFusedRows((const mfsr_float3*)((const char*)imgOut + off), (const mfsr_float3*)((const char*)totalWeights + off),
+                                 12 * L.hrW, (const mfsr_float3*)L.fallback.ptr, L.fallback.pitch, L.W, L.H, 0.0f, 1.0f, 0.0f, 1.0f,
+                                 nullptr, 12 * L.hrW, out16Dev + (size_t)r0 * L.hrW * 3, L.hrW, r1 - r0, c.weightThreshold,
+                                 c.applyGamma, 65535.0f, r0, L.hrH, stream));
+        if (!b->evBand[i]) MFSR_HIP_TRY(hipEventCreateWithFlags(&b->evBand[i], hipEventDisableTiming));
+        MFSR_HIP_TRY(hipEventRecord(b->evBand[i], mfsr_s(stream)));
+        MFSR_HIP_TRY(hipStreamWaitEvent(b->downStream, b->evBand[i], 0));
+        MFSR_HIP_TRY(hipMemcpy2DAsync((char*)out16Host + (size_t)r0 * rowBytes, rowBytes, (const char*)out16Dev + (size_t)r0 * rowBytes,
+                                      rowBytes, rowBytes, (size_t)(r1 - r0), hipMemcpyDeviceToHost, b->downStream));
+    }
+    if (heldGroup && b->copyStream) {
+        // upload slots whose raw frame these launches were the last to read
+        for (int j = 0; j < p.n; j++) {
+            const int us = upload_slot_of(b, p.raw[j]);
+            if (us >= 0) {
+                MFSR_HIP_TRY(hipEventRecord(b->evFree[us], mfsr_s(stream)));
+                b->freeRecorded[us] = true;
+            }
+        }
+    }
     MFSR_HIP_TRY(hipEventRecord(b->evDown, b->downStream));
     b->downRecorded = true;
     return MFSR_OK;
