@@ -654,9 +654,11 @@ extern "C" int mfsr_lucasKanadeSweepBatch(int nFrames, const mfsr_lk_frame* fram
         const char* e = getenv("MFSR_LK_BAND");
         return e ? atoi(e) : 0;
     }();
-    int band = (int)((long long)height * strips * nFrames / 4096);
-    band = band < 16 ? 16 : (band > 64 ? 64 : band);
-    band &= ~7;
+    // (measured at 1920 x 1080, h = 3: one frame 27.0 / 32.5 / 48.8 us with bands of 8 / 16 / 32 rows, four frames 27.1 / 26.5 /
+    // 27.6 us per frame: the wave count decides, the halo rows cost less than idle SIMDs)
+    int band = (int)((long long)height * strips * nFrames / 8192);
+    band = (band + 4) & ~7;
+    band = band < 8 ? 8 : (band > 64 ? 64 : band);
     if (forceBand >= 8) band = forceBand;
     dim3 grid(strips, mfsr_cdiv(height, band), nFrames), block(64);
 #define LKS_CASE(HT)                                                                                                          \

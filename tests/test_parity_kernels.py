@@ -1001,7 +1001,7 @@ def test_lucasKanadeIterationWarped_is_bit_identical(hip, hw, W, H):
         assert np.abs(want).max() > 0.5
 
 
-@pytest.mark.parametrize("hw,W,H,nf", [(3, 100, 70, 1), (3, 333, 141, 3), (2, 64, 40, 2), (5, 130, 90, 4), (3, 1920, 1080, 4)])
+@pytest.mark.parametrize("hw,W,H,nf", [(3, 100, 70, 1), (3, 333, 141, 3), (2, 64, 40, 2), (5, 130, 90, 4), (3, 1920, 1080, 4), (3, 1920, 1080, 1)])
 def test_lucasKanadeSweepBatch_matches_the_tile_kernel(hip, hw, W, H, nf):
     """mfsr_lucasKanadeSweepBatch (k_lkSweep: register / DPP column sweep, several frames per launch) against
     mfsr_lucasKanadeIterationWarped frame by frame, three chained iterations: same products, same column order, same solve
