@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -72,6 +73,9 @@ static bool read_png(const std::string& path, Image8& img)
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 6 ? 4 : ctype == 4 ? 2 : 0;
     if (!ch) return false;
     const size_t stride = (size_t)w * ch;
+    // a deflate stream expands by at most ~1032 : 1: a header that promises more than the IDAT bytes can hold is refused
+    // BEFORE anything of that size is allocated (65 536 x 65 536 x 4 would be 17 GB)
+    if ((stride + 1) * (size_t)h > idat.size() * 1032 + 65536) return false;
     std::vector<uint8_t> rawpx((stride + 1) * h);
     uLongf dlen = rawpx.size();
     if (uncompress(rawpx.data(), &dlen, idat.data(), idat.size()) != Z_OK || dlen != rawpx.size()) return false;
@@ -109,16 +113,21 @@ static bool read_pnm(const std::string& path, Image8& img)
     size_t pos = 2;
     while (nv < 3 && pos < buf.size()) {
         while (pos < buf.size() && (buf[pos] == ' ' || buf[pos] == '\n' || buf[pos] == '\r' || buf[pos] == '\t')) pos++;
+        if (pos >= buf.size()) return false;  // the header ends in white space
         if (buf[pos] == '#') {
             while (pos < buf.size() && buf[pos] != '\n') pos++;
             continue;
         }
+        if (buf[pos] < '0' || buf[pos] > '9') return false;
         int v = 0;
-        while (pos < buf.size() && buf[pos] >= '0' && buf[pos] <= '9') v = v * 10 + (buf[pos++] - '0');
+        while (pos < buf.size() && buf[pos] >= '0' && buf[pos] <= '9') {
+            v = v * 10 + (buf[pos++] - '0');
+            if (v > 65535) return false;  // no overflow, and no frame this tool takes is larger
+        }
         vals[nv++] = v;
     }
-    pos++;
-    if (nv != 3 || vals[2] != 255) return false;
+    pos++;  // the single white-space byte after maxval
+    if (nv != 3 || vals[2] != 255 || vals[0] <= 0 || vals[1] <= 0 || pos > buf.size()) return false;
     img.w = vals[0];
     img.h = vals[1];
     img.ch = buf[1] == '5' ? 1 : 3;
@@ -225,7 +234,11 @@ static bool read_tiff(const std::string& path, Image8& img)
 static bool read_image(const std::string& path, Image8& img)
 {
     img.px16.clear();
-    return read_png(path, img) || read_pnm(path, img) || read_jpeg(path, img) || read_tiff(path, img);
+    try {  // the readers bound what they allocate by the file's size; an allocation failure is still a refusal, not an abort
+        return read_png(path, img) || read_pnm(path, img) || read_jpeg(path, img) || read_tiff(path, img);
+    } catch (const std::bad_alloc&) {
+        return false;
+    }
 }
 
 static void put32(std::vector<uint8_t>& v, uint32_t x)

@@ -181,6 +181,9 @@ inline bool decode_jpeg(const std::vector<uint8_t>& buf, int& w, int& h, int& ch
             w = (d[3] << 8) | d[4];
             nc = d[5];
             if ((nc != 1 && nc != 3) || w <= 0 || h <= 0 || w > 65500 || h > 65500 || dl < 6 + 3 * (size_t)nc) return false;
+            // every 8x8 block costs at least two Huffman codes (>= 2 bits) in the scan: a frame header that promises more
+            // blocks than the file's bits can encode is refused before its planes (up to 4 x 65500^2 bytes) are allocated
+            if ((size_t)w * (size_t)h / 64 > buf.size() * 4 + 1024) return false;
             for (int k = 0; k < nc; k++) {
                 comp[k].id = d[6 + 3 * k];
                 comp[k].h = d[7 + 3 * k] >> 4;

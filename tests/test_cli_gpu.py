@@ -136,6 +136,45 @@ def test_image_readers_against_an_independent_decoder(tmp_path):
     assert subprocess.run([conv, str(bad), str(tmp_path / "x.ppm")], capture_output=True).returncode != 0
 
 
+def test_image_readers_refuse_hostile_headers(tmp_path):
+    """Untrusted files: headers that promise far more pixels than the file can hold are refused before anything of that
+    size is allocated (PNG 65536^2 RGBA = 17 GB, JPEG SOF0 65500^2), a PNM header that ends in white space or overflows
+    its integers is refused without reading past the buffer -- exit code 1 from imgconv, never a crash (which would be a
+    negative return code) and never a multi-gigabyte allocation (checked through the address-space limit)."""
+    import struct
+    import zlib
+    conv = os.path.join(ROOT, "apps", "imgconv")
+    if not os.path.exists(conv):
+        pytest.skip("apps/imgconv not built")
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+    cases = {
+        "huge.png": b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 65536, 65536, 8, 6, 0, 0, 0))
+                    + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b""),
+        "ws.pgm": b"P5 12 12   \n  ",
+        "overflow.pgm": b"P5 99999999999999999999 4 255\n" + b"\0" * 64,
+        "zero.pgm": b"P5 0 4 255\n" + b"\0" * 64,
+        "neg.ppm": b"P6 -4 4 255\n" + b"\0" * 64,
+    }
+    jpg = bytearray(open(os.path.join(ROOT, "tests", "golden", "car/1.jpg"), "rb").read())
+    i = jpg.find(b"\xff\xc0")
+    assert i > 0
+    jpg[i + 5:i + 9] = struct.pack(">HH", 65500, 65500)      # SOF0: height, width
+    cases["huge.jpg"] = bytes(jpg)
+    import resource
+
+    def limit():
+        resource.setrlimit(resource.RLIMIT_AS, (2 << 30, 2 << 30))   # a 17 GB vector would throw; the readers must not even try
+
+    for name, data in cases.items():
+        f = tmp_path / name
+        f.write_bytes(data)
+        p = subprocess.run([conv, str(f), str(tmp_path / "o.ppm")], capture_output=True, preexec_fn=limit)
+        assert p.returncode == 1, (name, p.returncode, p.stderr[-200:])
+
+
 def _tiff_bytes(arr, big_endian, rows_per_strip):
     """Hand-written baseline TIFF (uncompressed, chunky) of a uint8 / uint16 array [h, w] or [h, w, c], several strips."""
     import struct
