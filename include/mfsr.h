@@ -388,6 +388,47 @@ int mfsr_lucasKanadeIterationWarped(const mfsr_float2* shiftsIn, mfsr_float2* sh
                                     const float* movedImg, int pitchImg, const float* sumIn, const float* diffIn, float* sumOut,
                                     float* diffOut, int pitchSD, int width, int height, int halfWindowSize, float minDet,
                                     float outScale, mfsr_stream_t stream);
+/* ---- frame batches: the per-frame stages of the alignment for 1 .. 4 moved frames against one reference in ONE launch each
+ * (gridDim.z = frame; the kernels are the single-frame entry points' own, so a frame's result does not depend on the batch it
+ * is in).  mfsr_burst_add_frame aligns the frames of a fuse group this way. */
+typedef struct {
+    const uint16_t* dataIn;
+    mfsr_float3* halfOut;
+    float* pyr0;
+    float* pyr1; /* NULL for all frames: no second pyramid level */
+} mfsr_prepare_frame;
+int mfsr_prepareFrameFusedBatch(int nFrames, const mfsr_prepare_frame* frames, int halfPitch, float maxVal, int dimX, int dimY,
+                                int pyr0Pitch, int pyr1Pitch, const float* taps, int ntaps, mfsr_stream_t stream);
+typedef struct {
+    const float* movedImg;
+    const mfsr_float2* coarseShifts; /* this frame's shifts of the coarser level (mfsr_trackTilesFusedUp); NULL for all: none */
+    mfsr_float2* coordinates;
+    const mfsr_prealign* base; /* or NULL */
+} mfsr_track_frame;
+int mfsr_trackTilesFastSupported(int tileSize, int maxShift); /* 1: mfsr_trackTilesFusedBatch takes this (tile size, search range) */
+int mfsr_trackTilesFusedBatch(int nFrames, const mfsr_track_frame* frames, const float* refImg, int coarsePitch, int oldLevel,
+                              int newLevel, int oldCountX, int oldCountY, int oldTileSize, int coordinatesPitch, int imgWidth,
+                              int imgHeight, int imgPitch, int maxShift, int tileSize, int tileCountX, int tileCountY, float threshold,
+                              const float* refSquaredSums, float baseInvScale, mfsr_stream_t stream);
+typedef struct {
+    mfsr_float2* outImg;
+    const mfsr_float2* tileShifts;
+    const mfsr_prealign* base; /* NULL for all frames, or set for all */
+    const float* movedImg;
+    float* sumOut;
+    float* diffOut;
+} mfsr_flowfield_frame;
+int mfsr_CreateFlowFieldWarpedBatch(int nFrames, const mfsr_flowfield_frame* frames, int tilePitch, int tileCountX, int tileCountY,
+                                    int imgWidth, int imgHeight, int imgPitch, const float* refImg, int pitchImg, int pitchSD,
+                                    mfsr_stream_t stream);
+typedef struct {
+    const mfsr_float3* movedHalf;
+    mfsr_float4* mask;
+    const mfsr_float2* flow;
+} mfsr_robustness_frame;
+int mfsr_robustnessMaskFusedBatch(int nFrames, const mfsr_robustness_frame* frames, const mfsr_float3* rawImgRef, int flowPitch,
+                                  int flowWidth, int flowHeight, int imgWidth, int imgHeight, int imgPitch, int maskPitch, float alpha,
+                                  float beta, float thresholdM, mfsr_stream_t stream);
 /* The iteration of mfsr_lucasKanadeIterationWarped for 1 .. 4 frames against one reference in ONE launch (csrc/lk_fused.hip,
  * k_lkSweep: one wavefront per 64 columns sweeping down a band of rows, vertical state in registers, horizontal window sums
  * through whole-wave DPP shifts, no LDS).  Agrees with mfsr_lucasKanadeIterationWarped to fp32 rounding (another

@@ -173,7 +173,8 @@ class _Lib:
             raise AttributeError(name)
         full = raw.__name__ if hasattr(raw, "__name__") else name
         ret = self.protos[full][0]
-        if ret != "int" or full in ("mfsr_version", "mfsr_device_count", "mfsr_gaussin_filter_1D", "mfsr_burst_group_size"):
+        if ret != "int" or full in ("mfsr_version", "mfsr_device_count", "mfsr_gaussin_filter_1D", "mfsr_burst_group_size",
+                                     "mfsr_trackTilesFastSupported"):
             return raw
 
         def checked(*a):

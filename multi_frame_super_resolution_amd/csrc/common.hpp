@@ -47,6 +47,12 @@ static inline hipStream_t mfsr_s(mfsr_stream_t s) { return (hipStream_t)s; }
 static inline unsigned mfsr_cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
 // ---- CFA pattern: packed 4 x 8 bit, [y%2][x%2] -> bits ((y&1)*2+(x&1))*8 -----
+// Frame batches: the per-frame pointer arguments of a kernel for up to MFSR_BATCH_MAX frames, appended to its argument list; a
+// launch with gridDim.z > 1 takes frame blockIdx.z's pointers from the table (a scalar load), a plain launch ignores it.
+#define MFSR_BATCH_MAX 4
+struct MfsrBatch {
+    const void* p[MFSR_BATCH_MAX][6];
+};
 int mfsr_cfa_packed();  // defined in debayer.hip (process-wide state)
 __device__ __forceinline__ int cfa_at(int packed, int y, int x) { return (packed >> ((((y & 1) << 1) | (x & 1)) << 3)) & 0xff; }
 

@@ -2,6 +2,7 @@
 // Behavioural spec: reference test_opencv/DeBayerKernels.cu:28-283.
 // These kernels use only + - * / fabs, so with -ffp-contract=off they are
 // bit-identical to the CPU oracle.
+#include <cstring>
 #include "common.hpp"
 
 // ---- A0: c_cfaPattern (DeBayerKernels.cu:40-41) -------------------------------
@@ -115,8 +116,14 @@ __device__ __forceinline__ pix3 a1_pixel(const uint16_t* __restrict__ dataIn, in
 __global__ void __launch_bounds__(256)
     k_prepareFrameFused(const uint16_t* __restrict__ dataIn, pix3* __restrict__ halfOut, int halfPitch, float maxVal,
                         int dimX, int dimY, float* __restrict__ pyr0, int pyr0Pitch, float* __restrict__ pyr1,
-                        int pyr1Pitch, PrepTaps taps, int cfa)
+                        int pyr1Pitch, PrepTaps taps, int cfa, MfsrBatch bt)
 {
+    if (gridDim.z > 1) {
+        dataIn = (const uint16_t*)bt.p[blockIdx.z][0];
+        halfOut = (pix3*)bt.p[blockIdx.z][1];
+        pyr0 = (float*)bt.p[blockIdx.z][2];
+        pyr1 = (float*)bt.p[blockIdx.z][3];
+    }
     extern __shared__ __attribute__((aligned(16))) float s_prep[];
     const int c0 = taps.n / 2;
     const int GW = PREP_TX + 2 * c0, GH = PREP_TY + 2 * c0;
@@ -172,25 +179,48 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-extern "C" int mfsr_prepareFrameFused(const uint16_t* dataIn, mfsr_float3* halfOut, int halfPitch, float maxVal, int dimX,
-                                      int dimY, float* pyr0, int pyr0Pitch, float* pyr1, int pyr1Pitch, const float* taps,
-                                      int ntaps, mfsr_stream_t stream)
+static int prepare_frames_impl(int n, const mfsr_prepare_frame* f, int halfPitch, float maxVal, int dimX, int dimY, int pyr0Pitch,
+                               int pyr1Pitch, const float* taps, int ntaps, mfsr_stream_t stream)
 {
-    MFSR_REQUIRE(dataIn && halfOut && pyr0 && taps && dimX > 0 && dimY > 0);
-    MFSR_REQUIRE((long long)halfPitch >= 12LL * dimX && (halfPitch & 3) == 0 && ((uintptr_t)dataIn & 3) == 0);
+    MFSR_REQUIRE(f && n >= 1 && n <= MFSR_BATCH_MAX && taps && dimX > 0 && dimY > 0);
+    MFSR_REQUIRE((long long)halfPitch >= 12LL * dimX && (halfPitch & 3) == 0);
     MFSR_REQUIRE((long long)pyr0Pitch >= 4LL * dimX && (pyr0Pitch & 3) == 0);
     MFSR_REQUIRE(ntaps > 0 && (ntaps & 1) == 1);
     if (ntaps / 2 > PREP_MAXC0) return MFSR_E_UNSUPPORTED;
-    if (pyr1) MFSR_REQUIRE((long long)pyr1Pitch >= 4LL * (dimX / 2) && (pyr1Pitch & 3) == 0 && dimX >= 2 && dimY >= 2);
+    MfsrBatch bt;
+    memset(&bt, 0, sizeof(bt));
+    for (int i = 0; i < n; i++) {
+        MFSR_REQUIRE(f[i].dataIn && f[i].halfOut && f[i].pyr0 && ((uintptr_t)f[i].dataIn & 3) == 0);
+        MFSR_REQUIRE((f[i].pyr1 != nullptr) == (f[0].pyr1 != nullptr));
+        bt.p[i][0] = f[i].dataIn;
+        bt.p[i][1] = f[i].halfOut;
+        bt.p[i][2] = f[i].pyr0;
+        bt.p[i][3] = f[i].pyr1;
+    }
+    if (f[0].pyr1) MFSR_REQUIRE((long long)pyr1Pitch >= 4LL * (dimX / 2) && (pyr1Pitch & 3) == 0 && dimX >= 2 && dimY >= 2);
     PrepTaps tp;
     tp.n = ntaps;
     for (int i = 0; i < ntaps; i++) tp.t[i] = taps[i];
     const int c0 = ntaps / 2, GW = PREP_TX + 2 * c0, GH = PREP_TY + 2 * c0;
     const size_t lds = sizeof(float) * ((size_t)GW * GH + (size_t)PREP_TX * GH + (size_t)PREP_TX * PREP_TY);
-    dim3 block(64, 4), grid(mfsr_cdiv(dimX, PREP_TX), mfsr_cdiv(dimY, PREP_TY));
-    hipLaunchKernelGGL(k_prepareFrameFused, grid, block, lds, mfsr_s(stream), dataIn, (pix3*)halfOut, halfPitch, maxVal, dimX,
-                       dimY, pyr0, pyr0Pitch, pyr1, pyr1Pitch, tp, mfsr_cfa_packed());
+    dim3 block(64, 4), grid(mfsr_cdiv(dimX, PREP_TX), mfsr_cdiv(dimY, PREP_TY), n);
+    hipLaunchKernelGGL(k_prepareFrameFused, grid, block, lds, mfsr_s(stream), f[0].dataIn, (pix3*)f[0].halfOut, halfPitch, maxVal, dimX,
+                       dimY, f[0].pyr0, pyr0Pitch, f[0].pyr1, pyr1Pitch, tp, mfsr_cfa_packed(), bt);
     return mfsr_launch_status("prepareFrameFused");
+}
+
+extern "C" int mfsr_prepareFrameFused(const uint16_t* dataIn, mfsr_float3* halfOut, int halfPitch, float maxVal, int dimX,
+                                      int dimY, float* pyr0, int pyr0Pitch, float* pyr1, int pyr1Pitch, const float* taps,
+                                      int ntaps, mfsr_stream_t stream)
+{
+    const mfsr_prepare_frame f = {dataIn, halfOut, pyr0, pyr1};
+    return prepare_frames_impl(1, &f, halfPitch, maxVal, dimX, dimY, pyr0Pitch, pyr1Pitch, taps, ntaps, stream);
+}
+
+extern "C" int mfsr_prepareFrameFusedBatch(int nFrames, const mfsr_prepare_frame* frames, int halfPitch, float maxVal, int dimX, int dimY,
+                                           int pyr0Pitch, int pyr1Pitch, const float* taps, int ntaps, mfsr_stream_t stream)
+{
+    return prepare_frames_impl(nFrames, frames, halfPitch, maxVal, dimX, dimY, pyr0Pitch, pyr1Pitch, taps, ntaps, stream);
 }
 
 // ---- A2: deBayerGreenKernel (DeBayerKernels.cu:55-149) ------------------------

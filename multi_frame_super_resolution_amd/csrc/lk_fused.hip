@@ -374,8 +374,16 @@ __global__ void __launch_bounds__(256)
     k_flowFieldWarped(float2* __restrict__ outImg, mfsr_tex2d texShift, int imgWidth, int imgHeight, int imgPitch, float2 baseShift,
                       float baseRotation, const mfsr_prealign* __restrict__ base, const float* __restrict__ refImg,
                       const float* __restrict__ movedImg, int pitchImg, float* __restrict__ sumOut, float* __restrict__ diffOut,
-                      int pitchSD)
+                      int pitchSD, MfsrBatch bt)
 {
+    if (gridDim.z > 1) {
+        outImg = (float2*)bt.p[blockIdx.z][0];
+        texShift.ptr = bt.p[blockIdx.z][1];
+        base = (const mfsr_prealign*)bt.p[blockIdx.z][2];
+        movedImg = (const float*)bt.p[blockIdx.z][3];
+        sumOut = (float*)bt.p[blockIdx.z][4];
+        diffOut = (float*)bt.p[blockIdx.z][5];
+    }
     const int pxX = blockIdx.x * blockDim.x + threadIdx.x;
     const int pxY = blockIdx.y * blockDim.y + threadIdx.y;
     if (pxX >= imgWidth || pxY >= imgHeight) return;
@@ -412,25 +420,60 @@ __global__ void __launch_bounds__(256)
     row_ptr(diffOut, pitchSD, pxY)[pxX] = wv - rv;
 }
 
+static int flow_field_warped_impl(int n, const mfsr_flowfield_frame* f, int tilePitch, int tileW, int tileH, int imgWidth, int imgHeight,
+                                  int imgPitch, mfsr_float2 baseShift, float baseRotation, const float* refImg, int pitchImg, int pitchSD,
+                                  mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(f && n >= 1 && n <= MFSR_BATCH_MAX && refImg && imgWidth >= 2 && imgHeight >= 2);
+    MFSR_REQUIRE((long long)imgPitch >= 8LL * imgWidth && (imgPitch & 7) == 0);
+    MFSR_REQUIRE((long long)pitchImg >= 4LL * imgWidth && (pitchImg & 3) == 0 && (long long)pitchSD >= 4LL * imgWidth && (pitchSD & 3) == 0);
+    mfsr_tex2d tex;
+    tex.ptr = f[0].tileShifts;
+    tex.pitch = tilePitch;
+    tex.width = tileW;
+    tex.height = tileH;
+    MFSR_REQUIRE(mfsr_tex_ok(tex, 8) && (tilePitch & 7) == 0);
+    MfsrBatch bt;
+    memset(&bt, 0, sizeof(bt));
+    for (int i = 0; i < n; i++) {
+        MFSR_REQUIRE(f[i].outImg && f[i].tileShifts && f[i].movedImg && f[i].sumOut && f[i].diffOut);
+        MFSR_REQUIRE(((uintptr_t)f[i].outImg & 7) == 0 && ((uintptr_t)f[i].tileShifts & 7) == 0);
+        MFSR_REQUIRE((f[i].base != nullptr) == (f[0].base != nullptr));
+        bt.p[i][0] = f[i].outImg;
+        bt.p[i][1] = f[i].tileShifts;
+        bt.p[i][2] = f[i].base;
+        bt.p[i][3] = f[i].movedImg;
+        bt.p[i][4] = f[i].sumOut;
+        bt.p[i][5] = f[i].diffOut;
+    }
+    dim3 block(64, 4), grid(mfsr_cdiv(imgWidth, 64), mfsr_cdiv(imgHeight, 4), n);
+    if (f[0].base)
+        hipLaunchKernelGGL(k_flowFieldWarped<true>, grid, block, 0, mfsr_s(stream), (float2*)f[0].outImg, tex, imgWidth, imgHeight, imgPitch,
+                           make_float2(0.0f, 0.0f), 0.0f, f[0].base, refImg, f[0].movedImg, pitchImg, f[0].sumOut, f[0].diffOut, pitchSD, bt);
+    else
+        hipLaunchKernelGGL(k_flowFieldWarped<false>, grid, block, 0, mfsr_s(stream), (float2*)f[0].outImg, tex, imgWidth, imgHeight, imgPitch,
+                           make_float2(baseShift.x, baseShift.y), baseRotation, f[0].base, refImg, f[0].movedImg, pitchImg, f[0].sumOut,
+                           f[0].diffOut, pitchSD, bt);
+    return mfsr_launch_status("CreateFlowFieldWarped");
+}
+
 extern "C" int mfsr_CreateFlowFieldWarped(mfsr_float2* outImg, mfsr_tex2d texObjShiftXY, int imgWidth, int imgHeight, int imgPitch,
                                           mfsr_float2 baseShift, float baseRotation, const mfsr_prealign* base, const float* refImg,
                                           const float* movedImg, int pitchImg, float* sumOut, float* diffOut, int pitchSD,
                                           mfsr_stream_t stream)
 {
-    MFSR_REQUIRE(outImg && refImg && movedImg && sumOut && diffOut && imgWidth > 0 && imgHeight > 0);
-    MFSR_REQUIRE((long long)imgPitch >= 8LL * imgWidth && (imgPitch & 7) == 0 && ((uintptr_t)outImg & 7) == 0);
-    MFSR_REQUIRE((long long)pitchImg >= 4LL * imgWidth && (pitchImg & 3) == 0 && (long long)pitchSD >= 4LL * imgWidth && (pitchSD & 3) == 0);
-    MFSR_REQUIRE(mfsr_tex_ok(texObjShiftXY, 8) && ((uintptr_t)texObjShiftXY.ptr & 7) == 0 && (texObjShiftXY.pitch & 7) == 0);
-    MFSR_REQUIRE(imgWidth >= 2 && imgHeight >= 2);
-    dim3 block(64, 4), grid(mfsr_cdiv(imgWidth, 64), mfsr_cdiv(imgHeight, 4));
-    if (base)
-        hipLaunchKernelGGL(k_flowFieldWarped<true>, grid, block, 0, mfsr_s(stream), (float2*)outImg, texObjShiftXY, imgWidth, imgHeight,
-                           imgPitch, make_float2(0.0f, 0.0f), 0.0f, base, refImg, movedImg, pitchImg, sumOut, diffOut, pitchSD);
-    else
-        hipLaunchKernelGGL(k_flowFieldWarped<false>, grid, block, 0, mfsr_s(stream), (float2*)outImg, texObjShiftXY, imgWidth, imgHeight,
-                           imgPitch, make_float2(baseShift.x, baseShift.y), baseRotation, base, refImg, movedImg, pitchImg, sumOut,
-                           diffOut, pitchSD);
-    return mfsr_launch_status("CreateFlowFieldWarped");
+    const mfsr_flowfield_frame f = {outImg, (const mfsr_float2*)texObjShiftXY.ptr, base, movedImg, sumOut, diffOut};
+    return flow_field_warped_impl(1, &f, texObjShiftXY.pitch, texObjShiftXY.width, texObjShiftXY.height, imgWidth, imgHeight, imgPitch,
+                                  baseShift, baseRotation, refImg, pitchImg, pitchSD, stream);
+}
+
+extern "C" int mfsr_CreateFlowFieldWarpedBatch(int nFrames, const mfsr_flowfield_frame* frames, int tilePitch, int tileCountX,
+                                               int tileCountY, int imgWidth, int imgHeight, int imgPitch, const float* refImg,
+                                               int pitchImg, int pitchSD, mfsr_stream_t stream)
+{
+    const mfsr_float2 z = {0.0f, 0.0f};
+    return flow_field_warped_impl(nFrames, frames, tilePitch, tileCountX, tileCountY, imgWidth, imgHeight, imgPitch, z, 0.0f, refImg,
+                                  pitchImg, pitchSD, stream);
 }
 
 // ---- the same iteration as a register / DPP column sweep, for up to MFSR_LK_MAX_BATCH frames per launch -----------------------

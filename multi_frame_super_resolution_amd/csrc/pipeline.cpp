@@ -1027,6 +1027,89 @@ static int align_deferred(mfsr_burst* b, mfsr_stream_t stream)
     for (int i = 0; i < b->pend.n; i++)
         if (b->pend.deferred[i]) idx[n++] = i;
     if (n == 0) return MFSR_OK;
+    // the moved-frame intermediates of batch position q (0: the Layout's own members, q > 0: align set q - 1)
+    auto movHalf = [&](int q) -> Img& { return q == 0 ? L.movHalf : L.sets[q - 1].movHalf; };
+    auto movPyr = [&](int q) -> Img* { return q == 0 ? L.movPyr : L.sets[q - 1].movPyr; };
+    auto shiftsOf = [&](int q) -> Img* { return q == 0 ? L.shifts : L.sets[q - 1].shifts; };
+    auto lkSumOf = [&](int q) -> Img* { return q == 0 ? L.lkSum : L.sets[q - 1].lkSum; };
+    auto lkDiffOf = [&](int q) -> Img* { return q == 0 ? L.lkDiff : L.sets[q - 1].lkDiff; };
+    // Every per-frame stage as ONE launch over the batch (gridDim.z = frame) where the default kernels apply: the fused prepare
+    // kernel, the compile-time tracker at every level, the flow field + first warp, later the fused robustness kernel.
+    // Anything else (monochrome frames, pre-alignment, other tile sizes) runs the same stages frame by frame.
+    static const bool stageBatchOn = [] {
+        const char* e = getenv("MFSR_ALIGN_BATCH");
+        return !(e && e[0] == '1' && e[1] == 's');  // MFSR_ALIGN_BATCH=1s: batch the Lucas-Kanade launches only (A/B)
+    }();
+    const int nlev = ilog2(L.maxFactor) + 1;
+    bool stageBatch = stageBatchOn && c.fused && !c.mono && !c.preAlign && b->ntaps / 2 <= 8 && L.tw == L.hw && L.th == L.hh;
+    for (int l = 0; l < c.levels && stageBatch; l++) stageBatch = mfsr_trackTilesFastSupported(c.tileSize[l], c.maxShift[l]) != 0;
+    int mq[MFSR_MAX_FUSE_GROUP], m = 0;  // batch positions of the moved (non-reference) frames
+    for (int q = 0; q < n; q++)
+        if (!b->pend.isRef[idx[q]]) mq[m++] = q;
+    if (stageBatch) {
+        for (int q = 0; q < n; q++) {
+            const int i = idx[q], slot = b->pend.slot[i];
+            if (b->pend.isRef[i]) {  // identity flow, certainty 1 (and the slot wait) through the frame path
+                Img *flow = nullptr, *mask = nullptr;
+                TRY(align_frame(b, b->pend.raw[i], 1, slot, &flow, &mask, stream, ALIGN_PRE));
+            } else if (b->fuseStream && b->fusedOutstanding[slot]) {
+                // the slot's buffers are free once the fuse that read them last has run
+                MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evFused[slot], 0));
+                b->fusedOutstanding[slot] = false;
+            }
+        }
+        if (m > 0) {
+            TRY(mfsr_set_cfa_pattern(c.cfa));
+            // A1 + luma + prefilter + first pyramid level
+            mfsr_prepare_frame pf[MFSR_MAX_FUSE_GROUP];
+            for (int k = 0; k < m; k++) {
+                Img* pyr = movPyr(mq[k]);
+                pf[k].dataIn = b->pend.raw[idx[mq[k]]];
+                pf[k].halfOut = (mfsr_float3*)movHalf(mq[k]).ptr;
+                pf[k].pyr0 = (float*)pyr[0].ptr;
+                pf[k].pyr1 = nlev > 1 ? (float*)pyr[1].ptr : nullptr;
+            }
+            TRY(mfsr_prepareFrameFusedBatch(m, pf, L.movHalf.pitch, c.maxVal, L.hw, L.hh, L.movPyr[0].pitch, nlev > 1 ? L.movPyr[1].pitch : 0,
+                                            b->taps, b->ntaps, stream));
+            for (int k = 0; k < m; k++) {
+                Img* pyr = movPyr(mq[k]);
+                for (int i = 2; i < nlev; i++)
+                    TRY(mfsr_downsample2x((const float*)pyr[i - 1].ptr, pyr[i - 1].pitch, (float*)pyr[i].ptr, pyr[i].pitch, pyr[i].w, pyr[i].h,
+                                          stream));
+            }
+            // B: coarse -> fine, one launch per level
+            for (int l = 0; l < c.levels; l++) {
+                const int pi = ilog2(c.levelFactor[l]);
+                mfsr_track_frame tf[MFSR_MAX_FUSE_GROUP];
+                for (int k = 0; k < m; k++) {
+                    tf[k].movedImg = (const float*)movPyr(mq[k])[pi].ptr;
+                    tf[k].coarseShifts = l > 0 ? (const mfsr_float2*)shiftsOf(mq[k])[l - 1].ptr : nullptr;
+                    tf[k].coordinates = (mfsr_float2*)shiftsOf(mq[k])[l].ptr;
+                    tf[k].base = nullptr;
+                }
+                const Img& ref = L.refPyr[pi];
+                TRY(mfsr_trackTilesFusedBatch(m, tf, (const float*)ref.ptr, l > 0 ? L.shifts[l - 1].pitch : 0, l > 0 ? c.levelFactor[l - 1] : 0,
+                                              c.levelFactor[l], l > 0 ? L.tcx[l - 1] : 0, l > 0 ? L.tcy[l - 1] : 0,
+                                              l > 0 ? c.tileSize[l - 1] : 0, L.shifts[l].pitch, ref.w, ref.h, ref.pitch, c.maxShift[l],
+                                              c.tileSize[l], L.tcx[l], L.tcy[l], c.minimumThreshold, L.refSq[l],
+                                              1.0f / (float)c.levelFactor[l], stream));
+            }
+            // D1 + the first warp
+            const int last = c.levels - 1;
+            mfsr_flowfield_frame ff[MFSR_MAX_FUSE_GROUP];
+            for (int k = 0; k < m; k++) {
+                const int slot = b->pend.slot[idx[mq[k]]];
+                ff[k].outImg = (mfsr_float2*)L.flowBuf[2 * slot].ptr;
+                ff[k].tileShifts = (const mfsr_float2*)shiftsOf(mq[k])[last].ptr;
+                ff[k].base = nullptr;
+                ff[k].movedImg = (const float*)movPyr(mq[k])[0].ptr;
+                ff[k].sumOut = (float*)lkSumOf(mq[k])[0].ptr;
+                ff[k].diffOut = (float*)lkDiffOf(mq[k])[0].ptr;
+            }
+            TRY(mfsr_CreateFlowFieldWarpedBatch(m, ff, L.shifts[last].pitch, L.shifts[last].w, L.shifts[last].h, L.tw, L.th,
+                                                L.flowBuf[0].pitch, (const float*)L.refPyr[0].ptr, L.refPyr[0].pitch, L.lkSum[0].pitch, stream));
+        }
+    } else {
     // per-frame stages up to the flow field + first warp; frame q > 0 of the batch works in align set q - 1
     for (int q = 0; q < n; q++) {
         const int i = idx[q];
@@ -1035,6 +1118,7 @@ static int align_deferred(mfsr_burst* b, mfsr_stream_t stream)
         const int rc = align_frame(b, b->pend.raw[i], b->pend.isRef[i], b->pend.slot[i], &flow, &mask, stream, ALIGN_PRE);
         if (q > 0) swap_set(L, L.sets[q - 1]);
         if (rc) return rc;
+    }
     }
     // every Lucas-Kanade iteration of the batch in one launch
     bool batched = true;
@@ -1069,12 +1153,28 @@ static int align_deferred(mfsr_burst* b, mfsr_stream_t stream)
             return rc;
     }
     // robustness masks (and, without the batch kernel, the iterations frame by frame)
+    bool maskBatch = stageBatch && batched && m > 0;
+    if (maskBatch) {
+        mfsr_robustness_frame rf[MFSR_MAX_FUSE_GROUP];
+        for (int k = 0; k < m; k++) {
+            const int slot = b->pend.slot[idx[mq[k]]];
+            rf[k].movedHalf = (const mfsr_float3*)movHalf(mq[k]).ptr;
+            rf[k].mask = (mfsr_float4*)L.maskBuf[slot].ptr;
+            rf[k].flow = (const mfsr_float2*)L.flowBuf[2 * slot + (c.lkIterations & 1)].ptr;  // where the ping-pong ends
+        }
+        const int rc = mfsr_robustnessMaskFusedBatch(m, rf, (const mfsr_float3*)L.refHalf.ptr, L.flowBuf[0].pitch, L.tw, L.th, L.hw, L.hh,
+                                                     L.refHalf.pitch, L.maskBuf[0].pitch, c.alpha, c.beta, c.thresholdM, stream);
+        if (rc == MFSR_E_UNSUPPORTED)
+            maskBatch = false;  // (the straight robustness kernel was selected: frame by frame below)
+        else if (rc)
+            return rc;
+    }
     for (int q = 0; q < n; q++) {
         const int i = idx[q];
         if (q > 0) swap_set(L, L.sets[q - 1]);
         Img *flow = nullptr, *mask = nullptr;
         const int rc = align_frame(b, b->pend.raw[i], b->pend.isRef[i], b->pend.slot[i], &flow, &mask, stream,
-                                   batched ? ALIGN_POST : (ALIGN_LK | ALIGN_POST));
+                                   maskBatch ? 0 : (batched ? ALIGN_POST : (ALIGN_LK | ALIGN_POST)));
         if (q > 0) swap_set(L, L.sets[q - 1]);
         if (rc) return rc;
         b->pend.flow[i] = flow;

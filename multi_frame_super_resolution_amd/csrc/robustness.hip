@@ -6,6 +6,7 @@
 // stay in VGPRs.  Quirk kept: of the 25 flow fetches only the last one
 // (x=2,y=2) can influence min/max (:62-72), so only that one is issued -- the
 // other 24 are dead in the reference too.
+#include <cstring>
 #include "common.hpp"
 
 // x / 9 and x / 3 as reciprocal multiply + one fma correction (3 instructions instead of the ~11 of the
@@ -135,8 +136,13 @@ template <bool ALIGNED>
 __global__ void __launch_bounds__(RB_TX* RB_TY)
     k_robustnessFused(const pix3* __restrict__ rawImgRef, const pix3* __restrict__ rawImgMoved, float4* __restrict__ robustnessMask,
                       mfsr_tex2d texUV, int imgWidth, int imgHeight, int imgPitch, int maskPitch, float alpha, float beta,
-                      float thresholdM)
+                      float thresholdM, MfsrBatch bt)
 {
+    if (gridDim.z > 1) {
+        rawImgMoved = (const pix3*)bt.p[blockIdx.z][0];
+        robustnessMask = (float4*)bt.p[blockIdx.z][1];
+        texUV.ptr = bt.p[blockIdx.z][2];
+    }
     __shared__ float sR[3][RB_TY + 2][RB_TX + 2];
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int x0 = blockIdx.x * RB_TX, y0 = blockIdx.y * RB_TY;
@@ -247,14 +253,50 @@ extern "C" int mfsr_robustnessMaskFused(const mfsr_float3* rawImgRef, const mfsr
         return mfsr_ComputeRobustnessMask(rawImgRef, rawImgMoved, robustnessMask, texUV, imgWidth, imgHeight, imgPitch, maskPitch,
                                           alpha, beta, thresholdM, stream);
     }
+    MfsrBatch bt;
+    memset(&bt, 0, sizeof(bt));
     dim3 block(RB_TX, RB_TY), grid(mfsr_cdiv(imgWidth, RB_TX), mfsr_cdiv(imgHeight, RB_TY));
     if (texUV.width == imgWidth && texUV.height == imgHeight)
         hipLaunchKernelGGL(k_robustnessFused<true>, grid, block, 0, mfsr_s(stream), (const pix3*)rawImgRef, (const pix3*)rawImgMoved,
-                           (float4*)robustnessMask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM);
+                           (float4*)robustnessMask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM, bt);
     else
         hipLaunchKernelGGL(k_robustnessFused<false>, grid, block, 0, mfsr_s(stream), (const pix3*)rawImgRef, (const pix3*)rawImgMoved,
-                           (float4*)robustnessMask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM);
+                           (float4*)robustnessMask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM, bt);
     return mfsr_launch_status("robustnessMaskFused");
+}
+
+// mfsr_robustnessMaskFused for 1 .. 4 moved frames against one reference in one launch (the fused kernel only)
+extern "C" int mfsr_robustnessMaskFusedBatch(int nFrames, const mfsr_robustness_frame* frames, const mfsr_float3* rawImgRef, int flowPitch,
+                                             int flowWidth, int flowHeight, int imgWidth, int imgHeight, int imgPitch, int maskPitch,
+                                             float alpha, float beta, float thresholdM, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(frames && nFrames >= 1 && nFrames <= MFSR_BATCH_MAX && rawImgRef && imgWidth > 2 && imgHeight > 2);
+    MFSR_REQUIRE((long long)imgPitch >= 12LL * imgWidth && (imgPitch & 3) == 0);
+    MFSR_REQUIRE((long long)maskPitch >= 16LL * imgWidth && (maskPitch & 15) == 0);
+    if (!g_robustness_fast) return MFSR_E_UNSUPPORTED;
+    mfsr_tex2d texUV;
+    texUV.ptr = frames[0].flow;
+    texUV.pitch = flowPitch;
+    texUV.width = flowWidth;
+    texUV.height = flowHeight;
+    MFSR_REQUIRE(mfsr_tex_ok(texUV, 8) && (flowPitch & 7) == 0);
+    MfsrBatch bt;
+    memset(&bt, 0, sizeof(bt));
+    for (int i = 0; i < nFrames; i++) {
+        MFSR_REQUIRE(frames[i].movedHalf && frames[i].mask && frames[i].flow);
+        MFSR_REQUIRE(((uintptr_t)frames[i].mask & 15) == 0 && ((uintptr_t)frames[i].flow & 7) == 0);
+        bt.p[i][0] = frames[i].movedHalf;
+        bt.p[i][1] = frames[i].mask;
+        bt.p[i][2] = frames[i].flow;
+    }
+    dim3 block(RB_TX, RB_TY), grid(mfsr_cdiv(imgWidth, RB_TX), mfsr_cdiv(imgHeight, RB_TY), nFrames);
+    if (flowWidth == imgWidth && flowHeight == imgHeight)
+        hipLaunchKernelGGL(k_robustnessFused<true>, grid, block, 0, mfsr_s(stream), (const pix3*)rawImgRef, (const pix3*)frames[0].movedHalf,
+                           (float4*)frames[0].mask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM, bt);
+    else
+        hipLaunchKernelGGL(k_robustnessFused<false>, grid, block, 0, mfsr_s(stream), (const pix3*)rawImgRef, (const pix3*)frames[0].movedHalf,
+                           (float4*)frames[0].mask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM, bt);
+    return mfsr_launch_status("robustnessMaskFusedBatch");
 }
 
 extern "C" int mfsr_ComputeRobustnessMask(const mfsr_float3* rawImgRef, const mfsr_float3* rawImgMoved,

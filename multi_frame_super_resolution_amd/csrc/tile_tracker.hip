@@ -14,6 +14,7 @@
 
 #include <cstdlib>
 
+#include <cstring>
 #include "common.hpp"
 
 // ---- wavefront reductions -----------------------------------------------------
@@ -937,8 +938,14 @@ __global__ void __launch_bounds__((TrkFast<T, S, TPW>::threads))
                      int preShiftPitch, float2* __restrict__ coordinates, int coordinatesPitch, int imgWidth, int imgHeight,
                      int imgPitch, int tileCountX, int tileCountY, float threshold, const float* __restrict__ refSq,
                      const mfsr_prealign* __restrict__ base, float baseInvScale, const float2* __restrict__ coarse, int coarsePitch,
-                     int4 up, int upOldTile)
+                     int4 up, int upOldTile, MfsrBatch bt)
 {
+    if (gridDim.z > 1) {
+        movedImg = (const float*)bt.p[blockIdx.z][0];
+        coarse = (const float2*)bt.p[blockIdx.z][1];
+        coordinates = (float2*)bt.p[blockIdx.z][2];
+        base = (const mfsr_prealign*)bt.p[blockIdx.z][3];
+    }
     using G = TrkFast<T, S, TPW>;
     constexpr int L = G::L, R = G::R, Tp = G::Tp, Lp = G::Lp;
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
@@ -1135,8 +1142,14 @@ static int track_tiles_fused_impl(const float* refImg, const float* movedImg, co
                                   mfsr_float2* coordinates, int coordinatesPitch, int imgWidth, int imgHeight, int imgPitch,
                                   int maxShift, int tileSize, int tileCountX, int tileCountY, float threshold,
                                   const float* refSquaredSums, const mfsr_prealign* base, float baseInvScale,
-                                  const mfsr_float2* coarse, int coarsePitch, int4 up, int upOldTile, mfsr_stream_t stream)
+                                  const mfsr_float2* coarse, int coarsePitch, int4 up, int upOldTile, mfsr_stream_t stream,
+                                  int nFrames = 1, const MfsrBatch* batch = nullptr)
 {
+    MfsrBatch bt;
+    if (batch)
+        bt = *batch;
+    else
+        memset(&bt, 0, sizeof(bt));
     MFSR_REQUIRE(refImg && movedImg && coordinates && imgWidth > 0 && imgHeight > 0);
     MFSR_REQUIRE((long long)imgPitch >= 4LL * imgWidth && (imgPitch & 3) == 0);
     MFSR_REQUIRE(maxShift >= 1 && maxShift <= 15 && tileSize >= 4 && tileSize <= 128 && tileCountX > 0 && tileCountY > 0);
@@ -1152,10 +1165,11 @@ static int track_tiles_fused_impl(const float* refImg, const float* movedImg, co
 #define TRK_FAST_CASE(TT, SS, TPW)                                                                                       \
     if (fast && refSquaredSums && tileSize == TT && maxShift == SS) {                                                    \
         using G = TrkFast<TT, SS, TPW>;                                                                                  \
-        hipLaunchKernelGGL((k_trackTilesFast<TT, SS, TPW>), dim3(mfsr_cdiv(tileCountX * tileCountY, TPW)), dim3(G::threads), \
-                           G::ldsBytes, mfsr_s(stream), refImg, movedImg, (const float2*)preShift, preShiftPitch,         \
-                           (float2*)coordinates, coordinatesPitch, imgWidth, imgHeight, imgPitch, tileCountX, tileCountY,  \
-                           threshold, refSquaredSums, base, baseInvScale, (const float2*)coarse, coarsePitch, up, upOldTile); \
+        hipLaunchKernelGGL((k_trackTilesFast<TT, SS, TPW>), dim3(mfsr_cdiv(tileCountX * tileCountY, TPW), 1, nFrames),    \
+                           dim3(G::threads), G::ldsBytes, mfsr_s(stream), refImg, movedImg, (const float2*)preShift,      \
+                           preShiftPitch, (float2*)coordinates, coordinatesPitch, imgWidth, imgHeight, imgPitch, tileCountX, \
+                           tileCountY, threshold, refSquaredSums, base, baseInvScale, (const float2*)coarse, coarsePitch, \
+                           up, upOldTile, bt);                                                                            \
         return mfsr_launch_status("trackTilesFast");                                                                     \
     }
     TRK_FAST_CASE(32, 4, 2)
@@ -1163,6 +1177,7 @@ static int track_tiles_fused_impl(const float* refImg, const float* movedImg, co
     TRK_FAST_CASE(16, 4, 4)
     TRK_FAST_CASE(32, 8, 1)
 #undef TRK_FAST_CASE
+    if (nFrames > 1) return MFSR_E_UNSUPPORTED;  // frame batches run the compile-time kernel only
     static const int nsx = [] {
         const char* e = getenv("MFSR_TRK_NSX");
         return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 1;
@@ -1217,6 +1232,44 @@ extern "C" int mfsr_trackTilesFusedUp(const float* refImg, const float* movedImg
     return track_tiles_fused_impl(refImg, movedImg, nullptr, 0, coordinates, coordinatesPitch, imgWidth, imgHeight, imgPitch, maxShift,
                                   tileSize, tileCountX, tileCountY, threshold, refSquaredSums, base, baseInvScale, coarseShifts,
                                   coarsePitch, make_int4(oldLevel, newLevel, oldCountX, oldCountY), oldTileSize, stream);
+}
+
+// 1 if (tileSize, maxShift) runs the compile-time tracker kernel (the only one that takes frame batches)
+extern "C" int mfsr_trackTilesFastSupported(int tileSize, int maxShift)
+{
+    return (tileSize == 32 && maxShift == 4) || (tileSize == 16 && maxShift == 3) || (tileSize == 16 && maxShift == 4) ||
+           (tileSize == 32 && maxShift == 8);
+}
+
+// the tracker of one pyramid level for 1 .. 4 moved frames against one reference in ONE launch.  Every frame takes its pre-shifts
+// from its own coarser-level shifts (coarseShifts, as mfsr_trackTilesFusedUp) or, at the coarsest level, none (all NULL).
+// MFSR_E_UNSUPPORTED (nothing launched) unless (tileSize, maxShift) is one of the compile-time kernels' pairs.
+extern "C" int mfsr_trackTilesFusedBatch(int nFrames, const mfsr_track_frame* frames, const float* refImg, int coarsePitch, int oldLevel,
+                                         int newLevel, int oldCountX, int oldCountY, int oldTileSize, int coordinatesPitch, int imgWidth,
+                                         int imgHeight, int imgPitch, int maxShift, int tileSize, int tileCountX, int tileCountY,
+                                         float threshold, const float* refSquaredSums, float baseInvScale, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(frames && nFrames >= 1 && nFrames <= MFSR_BATCH_MAX && refSquaredSums);
+    MfsrBatch bt;
+    memset(&bt, 0, sizeof(bt));
+    const bool up = frames[0].coarseShifts != nullptr;
+    for (int i = 0; i < nFrames; i++) {
+        MFSR_REQUIRE(frames[i].movedImg && frames[i].coordinates && ((uintptr_t)frames[i].coordinates & 7) == 0);
+        MFSR_REQUIRE((frames[i].coarseShifts != nullptr) == up && ((uintptr_t)frames[i].coarseShifts & 7) == 0);
+        bt.p[i][0] = frames[i].movedImg;
+        bt.p[i][1] = frames[i].coarseShifts;
+        bt.p[i][2] = frames[i].coordinates;
+        bt.p[i][3] = frames[i].base;
+    }
+    if (up) {
+        MFSR_REQUIRE(oldLevel > 0 && newLevel > 0 && oldCountX > 0 && oldCountY > 0 && oldTileSize > 0);
+        MFSR_REQUIRE((long long)coarsePitch >= 8LL * oldCountX && (coarsePitch & 7) == 0);
+    }
+    return track_tiles_fused_impl(refImg, frames[0].movedImg, nullptr, 0, frames[0].coordinates, coordinatesPitch, imgWidth, imgHeight,
+                                  imgPitch, maxShift, tileSize, tileCountX, tileCountY, threshold, refSquaredSums, frames[0].base,
+                                  baseInvScale, frames[0].coarseShifts, coarsePitch,
+                                  up ? make_int4(oldLevel, newLevel, oldCountX, oldCountY) : make_int4(0, 0, 0, 0), up ? oldTileSize : 0,
+                                  stream, nFrames, &bt);
 }
 
 extern "C" int mfsr_trackTilesFused(const float* refImg, const float* movedImg, const mfsr_float2* preShift,
