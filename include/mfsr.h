@@ -574,6 +574,11 @@ int mfsr_burst_field_dims(const mfsr_burst* b, int* flowW, int* flowH, int* mask
 int mfsr_burst_align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float2* flowOut, int flowPitch,
                            mfsr_float4* maskOut, int maskPitch, mfsr_stream_t stream);
 /* frames per warp+fuse launch cfg.pairFrames stands for with this configuration (1 .. MFSR_MAX_FUSE_GROUP) */
+/* mfsr_burst_align_frame for nFrames frames (isReference: per-frame flags or NULL): groups of up to mfsr_burst_group_size
+ * frames share their launches (one per stage and Lucas-Kanade iteration); same results as frame by frame */
+int mfsr_burst_align_frames(mfsr_burst* b, int nFrames, const uint16_t* const* raws, const int* isReference,
+                            mfsr_float2* const* flowOut, int flowPitch, mfsr_float4* const* maskOut, int maskPitch,
+                            mfsr_stream_t stream);
 int mfsr_burst_group_size(const mfsr_config* cfg);
 /* stage G for 1 .. MFSR_MAX_FUSE_GROUP aligned frames on HR rows [rowBegin, rowEnd) (see mfsr_accumulateSuperResFullRows), with the kernel
  * parameters of the burst's reference */

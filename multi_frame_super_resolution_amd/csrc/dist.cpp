@@ -830,13 +830,26 @@ static int process_stripes(mfsr_dist* d, const uint16_t* const* frames, uint16_t
     // reference products on every rank, then this rank's frames: alignment only
     D_TRY(mfsr_burst_set_reference(d->burst, frames[ref], (mfsr_stream_t)st));
     std::vector<const uint16_t*> raws(N, nullptr);
-    for (int k = 0; k < N; k++) {
-        if (k % G != me) {
-            raws[k] = d->raw(k);
-            continue;
+    {
+        // this rank's frames, aligned in batches (one launch per stage for up to four frames)
+        std::vector<const uint16_t*> mineRaw;
+        std::vector<int> mineRef;
+        std::vector<mfsr_float2*> mineFlow;
+        std::vector<mfsr_float4*> mineMask;
+        for (int k = 0; k < N; k++) {
+            if (k % G != me) {
+                raws[k] = d->raw(k);
+                continue;
+            }
+            raws[k] = frames[k];
+            mineRaw.push_back(frames[k]);
+            mineRef.push_back(k == ref);
+            mineFlow.push_back(d->flow(k));
+            mineMask.push_back(d->mask(k));
         }
-        raws[k] = frames[k];
-        D_TRY(mfsr_burst_align_frame(d->burst, frames[k], k == ref, d->flow(k), L.flowPitch, d->mask(k), L.maskPitch, (mfsr_stream_t)st));
+        if (!mineRaw.empty())
+            D_TRY(mfsr_burst_align_frames(d->burst, (int)mineRaw.size(), mineRaw.data(), mineRef.data(), mineFlow.data(), L.flowPitch,
+                                          mineMask.data(), L.maskPitch, (mfsr_stream_t)st));
     }
 
     // exchange (on B, after the alignment on A).  (Receive buffers: B is past gather(i-1), which waited for fuse(i-1) -- the

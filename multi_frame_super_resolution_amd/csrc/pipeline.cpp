@@ -1266,6 +1266,59 @@ extern "C" int mfsr_burst_align_frame(mfsr_burst* b, const uint16_t* raw, int is
     return MFSR_OK;
 }
 
+// mfsr_burst_align_frame for several frames: groups of up to mfsr_burst_group_size frames are aligned as one batch (the
+// launches of mfsr_burst_add_frame's groups: a frame's result does not depend on the batch it is in)
+extern "C" int mfsr_burst_align_frames(mfsr_burst* b, int nFrames, const uint16_t* const* raws, const int* isReference,
+                                       mfsr_float2* const* flowOut, int flowPitch, mfsr_float4* const* maskOut, int maskPitch,
+                                       mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && raws && flowOut && maskOut && nFrames >= 0);
+    MFSR_REQUIRE(b->haveRef && !b->refStale);
+    MFSR_REQUIRE(b->pend.n == 0);  // no frame of an add_frame group may be waiting
+    Layout& L = b->L;
+    MFSR_REQUIRE((long long)flowPitch >= 8LL * L.tw && (flowPitch & 7) == 0);
+    MFSR_REQUIRE((long long)maskPitch >= 16LL * L.hw && (maskPitch & 15) == 0);
+    for (int k = 0; k < nFrames; k++)
+        MFSR_REQUIRE(raws[k] && flowOut[k] && maskOut[k] && ((uintptr_t)flowOut[k] & 7) == 0 && ((uintptr_t)maskOut[k] & 15) == 0);
+    TRY(mfsr_set_cfa_pattern(b->cfg.cfa));
+    const bool batch = can_defer_alignment(b);
+    const int per = batch ? b->group : 1;
+    for (int k0 = 0; k0 < nFrames; k0 += per) {
+        const int n = nFrames - k0 < per ? nFrames - k0 : per;
+        for (int j = 0; j < n; j++) {
+            const int isRef = isReference ? isReference[k0 + j] : 0;
+            const int slot = b->frameCounter++ % kRing;
+            b->pend.slot[j] = slot;
+            b->pend.raw[j] = raws[k0 + j];
+            b->pend.isRef[j] = isRef;
+            b->pend.deferred[j] = batch;
+            b->pend.flow[j] = nullptr;
+            b->pend.mask[j] = nullptr;
+            if (!batch) {
+                const int rc = align_frame(b, raws[k0 + j], isRef, slot, &b->pend.flow[j], &b->pend.mask[j], stream);
+                if (rc) {
+                    b->pend.n = 0;
+                    return rc;
+                }
+            }
+        }
+        b->pend.n = n;
+        const int rc = align_deferred(b, stream);
+        const mfsr_burst::Pending p = b->pend;
+        b->pend.n = 0;  // these frames are not waiting for a fuse
+        if (rc) return rc;
+        for (int j = 0; j < n; j++) {
+            b->flowCur = p.flow[j];
+            b->maskCur = p.mask[j];
+            MFSR_HIP_TRY(hipMemcpy2DAsync(flowOut[k0 + j], flowPitch, p.flow[j]->ptr, p.flow[j]->pitch, (size_t)L.tw * 8, L.th,
+                                          hipMemcpyDeviceToDevice, mfsr_s(stream)));
+            MFSR_HIP_TRY(hipMemcpy2DAsync(maskOut[k0 + j], maskPitch, p.mask[j]->ptr, p.mask[j]->pitch, (size_t)L.hw * 16, L.hh,
+                                          hipMemcpyDeviceToDevice, mfsr_s(stream)));
+        }
+    }
+    return MFSR_OK;
+}
+
 extern "C" int mfsr_burst_fuse_rows(mfsr_burst* b, int nFrames, const uint16_t* const* raws, const mfsr_float2* const* flows,
                                     int flowPitch, const mfsr_float4* const* masks, int maskPitch, mfsr_float3* imgOut,
                                     mfsr_float3* totalWeights, int accumulatorsUndefined, int rowBegin, int rowEnd,

@@ -82,8 +82,8 @@ def test_config_default_and_workspace():
     acc = L.raw["mfsr_burst_accumulator_bytes"](ctypes.byref(cfg))
     assert acc == 12 * 7680 * 4320          # 398 MB per plane-set
     assert 100e6 < ws < 2e9
-    cfg.fused = 0
-    assert L.raw["mfsr_burst_workspace_bytes"](ctypes.byref(cfg)) > ws
+    cfg.fused = 0   # the unfused chain: its own scratch images instead of the per-frame align sets of the batched path
+    assert 100e6 < L.raw["mfsr_burst_workspace_bytes"](ctypes.byref(cfg)) < 2e9
     cfg.width = 30                           # invalid geometry -> 0 bytes
     assert L.raw["mfsr_burst_workspace_bytes"](ctypes.byref(cfg)) == 0
 
