@@ -490,7 +490,8 @@ struct DistLayout {
     int flowPitch, maskPitch;
     size_t burstWs, accBytes, rawBytes, flowBytes, maskBytes, out16Bytes;
     size_t sendBytes, recvBytes;  // packed exchange buffers, sized for whole raw frames (the largest halo)
-    size_t offBurst, offImg, offTw, offRaw, offFlow, offMask, offOut16, offFlag, offSend, offRecv, total;
+    size_t offBurst, offBurst2, offImg, offTw, offRaw, offFlow, offMask, offOut16, offFlag, offSend, offRecv, total;
+    int sets;  // per-frame product buffer sets and burst contexts: 2 when bursts are pipelined (world > 1), else 1
 };
 
 // bytes of one frame's rows inside a packed message for the stripe `pl` (every piece 16-byte aligned)
@@ -548,12 +549,14 @@ int make_layout(const mfsr_config* c, int world, DistLayout* L)
         off += bytes;
         return o;
     };
+    L->sets = world > 1 ? 2 : 1;
     L->offBurst = take(L->burstWs);
+    L->offBurst2 = L->sets > 1 ? take(L->burstWs) : L->offBurst;
     L->offImg = take(L->accBytes);
     L->offTw = take(L->accBytes);
-    L->offRaw = take(up(L->rawBytes, 256) * L->N);
-    L->offFlow = take(up(L->flowBytes, 256) * L->N);
-    L->offMask = take(up(L->maskBytes, 256) * L->N);
+    L->offRaw = take(up(L->rawBytes, 256) * L->N * L->sets);
+    L->offFlow = take(up(L->flowBytes, 256) * L->N * L->sets);
+    L->offMask = take(up(L->maskBytes, 256) * L->N * L->sets);
     L->offOut16 = take(L->out16Bytes);
     L->offFlag = take(256 + sizeof(int) * (size_t)(world > 64 ? world : 64));
     L->offSend = take(L->sendBytes);
@@ -570,6 +573,7 @@ struct mfsr_dist {
     int rank, world, rawHalo, device;
     Transport* T;
     mfsr_burst* burst;
+    mfsr_burst* burst2;  // the second context of pipelined bursts (burst i works in context i & 1); == burst when not pipelined
     char* base;
     mfsr_float3 *imgOut, *totalWeights;
     uint16_t* out16;
@@ -577,14 +581,28 @@ struct mfsr_dist {
     // STRIPES: every transport call goes to commStream, in the same order on every rank (exchange i, gather i, exchange i+1, ..),
     // event-linked to the caller's stream, so that the gather of burst i overlaps the alignment of burst i+1
     hipStream_t commStream;
-    hipEvent_t evAligned, evExchanged, evFinished, evGathered;
+    hipEvent_t evAligned, evExchanged, evExchanged2, evFinished, evGathered;
+    // STRIPES, pipelined (world > 1, MFSR_DIST_PIPELINE != 0): process_burst(i) runs the reference products, the alignment and
+    // the exchange of burst i, then the fuse / finish / gather of burst i - 1 -- whose exchange completed long ago -- so the
+    // caller's stream never waits for an exchange; the last burst's back half runs in mfsr_dist_wait_output
+    int pipeline;
+    struct PendingBack {
+        bool has;
+        int ctx, rawHalo;
+        std::vector<const uint16_t*>* raws;
+        uint16_t* out16;
+        int* status;
+        int* flag;
+    } back;
     bool gatherPending;
     int overlap;
     long long burstNo;
     long long messagesSent, bytesSent;  // exchange + gather of the last burst (mfsr_dist_exchange_stats)
-    uint16_t* raw(int k) const { return (uint16_t*)(base + L.offRaw + up(L.rawBytes, 256) * (size_t)k); }
-    mfsr_float2* flow(int k) const { return (mfsr_float2*)(base + L.offFlow + up(L.flowBytes, 256) * (size_t)k); }
-    mfsr_float4* mask(int k) const { return (mfsr_float4*)(base + L.offMask + up(L.maskBytes, 256) * (size_t)k); }
+    int cur;  // product buffer set / burst context of the burst being enqueued
+    uint16_t* raw(int k) const { return (uint16_t*)(base + L.offRaw + up(L.rawBytes, 256) * ((size_t)cur * L.N + k)); }
+    mfsr_float2* flow(int k) const { return (mfsr_float2*)(base + L.offFlow + up(L.flowBytes, 256) * ((size_t)cur * L.N + k)); }
+    mfsr_float4* mask(int k) const { return (mfsr_float4*)(base + L.offMask + up(L.maskBytes, 256) * ((size_t)cur * L.N + k)); }
+    mfsr_burst* ctx() const { return cur ? burst2 : burst; }
     char* sendBuf() const { return base + L.offSend; }
     char* recvBuf() const { return base + L.offRecv; }
 };
@@ -616,10 +634,13 @@ static void dist_free(mfsr_dist* d)
     delete d->T;
     if (d->evAligned) (void)hipEventDestroy(d->evAligned);
     if (d->evExchanged) (void)hipEventDestroy(d->evExchanged);
+    if (d->evExchanged2) (void)hipEventDestroy(d->evExchanged2);
     if (d->evFinished) (void)hipEventDestroy(d->evFinished);
     if (d->evGathered) (void)hipEventDestroy(d->evGathered);
     if (d->commStream) (void)hipStreamDestroy(d->commStream);
+    if (d->burst2 && d->burst2 != d->burst) mfsr_burst_destroy(d->burst2);
     if (d->burst) mfsr_burst_destroy(d->burst);
+    delete d->back.raws;
     delete d;
 }
 
@@ -651,15 +672,23 @@ static int dist_new(mfsr_dist** out, const mfsr_config* cfg, int rank, int world
     d->flag = (int*)(d->base + d->L.offFlag);
     hipError_t he = hipGetDevice(&d->device);
     if (he == hipSuccess) rc = mfsr_burst_create(&d->burst, cfg, d->base + d->L.offBurst, d->L.burstWs);
+    d->burst2 = d->burst;
+    if (he == hipSuccess && rc == MFSR_OK && d->L.sets > 1)
+        rc = mfsr_burst_create(&d->burst2, cfg, d->base + d->L.offBurst2, d->L.burstWs);
+    d->back.raws = new (std::nothrow) std::vector<const uint16_t*>();
+    if (!d->back.raws && rc == MFSR_OK) rc = MFSR_E_INVALID;
     if (he != hipSuccess || rc != MFSR_OK) {
         dist_free(d);
         return he != hipSuccess ? (int)he : rc;
     }
     const char* e = getenv("MFSR_DIST_OVERLAP");
     d->overlap = (e && e[0] == '0') ? 0 : 1;
+    const char* ep = getenv("MFSR_DIST_PIPELINE");
+    d->pipeline = (d->L.sets > 1 && d->overlap && !(ep && ep[0] == '0')) ? 1 : 0;
     he = hipStreamCreateWithFlags(&d->commStream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&d->evAligned, hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&d->evExchanged, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&d->evExchanged2, hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&d->evFinished, hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&d->evGathered, hipEventDisableTiming);
     if (he != hipSuccess) {
@@ -813,6 +842,74 @@ static int exchange_rows(mfsr_dist* d, const std::vector<mfsr_stripe_plan>& plan
     return copy_segments(unpack, st);
 }
 
+// back half of a STRIPES burst whose products sit in set `ctx`: flow-bound check, every frame fused in frame order onto this
+// rank's HR rows, finish, gather of the u16 stripes onto rank 0, status
+static int stripes_back(mfsr_dist* d, int ctx, int rawHalo, const std::vector<const uint16_t*>& raws, uint16_t* out16, int* status, int* flag,
+                        hipStream_t st)
+{
+    const mfsr_config& c = d->cfg;
+    const DistLayout& L = d->L;
+    const int N = c.frames, G = d->world, me = d->rank;
+    std::vector<mfsr_stripe_plan> plan(G);
+    for (int p = 0; p < G; p++) D_TRY(mfsr_dist_stripe_plan(&c, G, p, rawHalo, &plan[p]));
+    const mfsr_stripe_plan& mine = plan[me];
+    hipStream_t B = d->overlap ? d->commStream : st;
+    const int saved = d->cur;
+    d->cur = ctx;
+    struct Restore {
+        mfsr_dist* d;
+        int v;
+        ~Restore() { d->cur = v; }
+    } restore{d, saved};
+    D_HIP(hipStreamWaitEvent(st, ctx ? d->evExchanged2 : d->evExchanged, 0));
+    // every frame, in frame order, a group per pass over the accumulators, onto this rank's HR rows only
+    if (mine.rowEnd > mine.rowBegin) {
+        // (a halo that spans the whole frame needs no check: every raw row is present)
+        for (int k = 0; k < N && mine.rawRows < c.height; k++)
+            D_TRY(mfsr_checkFlowBound((const mfsr_float2*)((const char*)d->flow(k) + (size_t)mine.flowRow0 * L.flowPitch), L.flowPitch, L.tw,
+                                      mine.flowRows, mine.maxFlowY, flag, (mfsr_stream_t)st));
+        const int per = mfsr_burst_group_size(&c);  // the grouping of the single-GPU burst: same sums in the same order
+        for (int k = 0; k < N; k += per) {
+            const int n = (k + per <= N) ? per : N - k;
+            const uint16_t* rg[MFSR_MAX_FUSE_GROUP];
+            const mfsr_float2* fg[MFSR_MAX_FUSE_GROUP];
+            const mfsr_float4* mg[MFSR_MAX_FUSE_GROUP];
+            for (int j = 0; j < n; j++) {
+                rg[j] = raws[k + j];
+                fg[j] = d->flow(k + j);
+                mg[j] = d->mask(k + j);
+            }
+            D_TRY(mfsr_burst_fuse_rows(d->ctx(), n, rg, fg, L.flowPitch, mg, L.maskPitch, d->imgOut, d->totalWeights, k == 0 ? 1 : 0,
+                                       mine.rowBegin, mine.rowEnd, (mfsr_stream_t)st));
+        }
+        uint16_t* dst = me == 0 ? out16 : d->out16;
+        // the staging image may still be on its way to rank 0 (gather of the previous burst, on B)
+        if (d->gatherPending) D_HIP(hipStreamWaitEvent(st, d->evGathered, 0));
+        D_TRY(mfsr_burst_finish_rows(d->ctx(), d->imgOut, d->totalWeights, nullptr, dst, mine.rowBegin, mine.rowEnd - mine.rowBegin,
+                                     (mfsr_stream_t)st));
+    }
+    // gather + status on B after the finish on A; the caller's stream does NOT wait for it (mfsr_dist_wait_output does):
+    // the next burst's alignment runs meanwhile
+    D_HIP(hipEventRecord(d->evFinished, st));
+    D_HIP(hipStreamWaitEvent(B, d->evFinished, 0));
+    if (G > 1) {
+        D_TRY(gather_stripes(d, plan, out16, B));
+        D_TRY(d->T->allReduceMaxI32(flag, B));
+    }
+    if (status) D_HIP(hipMemcpyAsync(status, flag, sizeof(int), hipMemcpyDeviceToDevice, B));
+    D_HIP(hipEventRecord(d->evGathered, B));
+    d->gatherPending = true;
+    return MFSR_OK;
+}
+
+// the back half of the burst that is still waiting for it (pipelined STRIPES bursts)
+static int drain_back(mfsr_dist* d, hipStream_t st)
+{
+    if (!d->back.has) return MFSR_OK;
+    d->back.has = false;
+    return stripes_back(d, d->back.ctx, d->back.rawHalo, *d->back.raws, d->back.out16, d->back.status, d->back.flag, st);
+}
+
 static int process_stripes(mfsr_dist* d, const uint16_t* const* frames, uint16_t* out16, int* status, hipStream_t st)
 {
     const mfsr_config& c = d->cfg;
@@ -820,15 +917,16 @@ static int process_stripes(mfsr_dist* d, const uint16_t* const* frames, uint16_t
     const int N = c.frames, G = d->world, me = d->rank, ref = c.reference;
     std::vector<mfsr_stripe_plan> plan(G);
     for (int p = 0; p < G; p++) D_TRY(mfsr_dist_stripe_plan(&c, G, p, d->rawHalo, &plan[p]));
-    const mfsr_stripe_plan& mine = plan[me];
-    int* flag = d->flag + (d->burstNo++ & 1);
+    int* flag = d->flag + (d->burstNo & 1);
+    d->cur = d->pipeline ? (int)(d->burstNo & 1) : 0;
+    d->burstNo++;
     d->messagesSent = d->bytesSent = 0;
     // A = the caller's stream (kernels), B = the comm stream (every transport call); with overlap off B = A
     hipStream_t B = d->overlap ? d->commStream : st;
     D_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
 
-    // reference products on every rank, then this rank's frames: alignment only
-    D_TRY(mfsr_burst_set_reference(d->burst, frames[ref], (mfsr_stream_t)st));
+    // front half: reference products on every rank, then this rank's frames: alignment only
+    D_TRY(mfsr_burst_set_reference(d->ctx(), frames[ref], (mfsr_stream_t)st));
     std::vector<const uint16_t*> raws(N, nullptr);
     {
         // this rank's frames, aligned in batches (one launch per stage for up to four frames)
@@ -848,56 +946,28 @@ static int process_stripes(mfsr_dist* d, const uint16_t* const* frames, uint16_t
             mineMask.push_back(d->mask(k));
         }
         if (!mineRaw.empty())
-            D_TRY(mfsr_burst_align_frames(d->burst, (int)mineRaw.size(), mineRaw.data(), mineRef.data(), mineFlow.data(), L.flowPitch,
+            D_TRY(mfsr_burst_align_frames(d->ctx(), (int)mineRaw.size(), mineRaw.data(), mineRef.data(), mineFlow.data(), L.flowPitch,
                                           mineMask.data(), L.maskPitch, (mfsr_stream_t)st));
     }
-
-    // exchange (on B, after the alignment on A).  (Receive buffers: B is past gather(i-1), which waited for fuse(i-1) -- the
-    // last reader of the per-frame buffers the unpack launch writes.)
+    // exchange (on B, after the alignment on A).  (Receive buffers of this set: their last reader was the fuse of the burst two
+    // calls ago, or of the previous one when bursts are not pipelined -- both are on A before the event B waits for here.)
     D_HIP(hipEventRecord(d->evAligned, st));
     D_HIP(hipStreamWaitEvent(B, d->evAligned, 0));
     if (G > 1) D_TRY(exchange_rows(d, plan, raws, B));
-    D_HIP(hipEventRecord(d->evExchanged, B));
-    D_HIP(hipStreamWaitEvent(st, d->evExchanged, 0));
+    D_HIP(hipEventRecord(d->cur ? d->evExchanged2 : d->evExchanged, B));
 
-    // every frame, in frame order, a group per pass over the accumulators, onto this rank's HR rows only
-    if (mine.rowEnd > mine.rowBegin) {
-        // (a halo that spans the whole frame needs no check: every raw row is present)
-        for (int k = 0; k < N && mine.rawRows < c.height; k++)
-            D_TRY(mfsr_checkFlowBound((const mfsr_float2*)((const char*)d->flow(k) + (size_t)mine.flowRow0 * L.flowPitch), L.flowPitch, L.tw,
-                                      mine.flowRows, mine.maxFlowY, flag, (mfsr_stream_t)st));
-        const int per = mfsr_burst_group_size(&c);  // the grouping of the single-GPU burst: same sums in the same order
-        for (int k = 0; k < N; k += per) {
-            const int n = (k + per <= N) ? per : N - k;
-            const uint16_t* rg[MFSR_MAX_FUSE_GROUP];
-            const mfsr_float2* fg[MFSR_MAX_FUSE_GROUP];
-            const mfsr_float4* mg[MFSR_MAX_FUSE_GROUP];
-            for (int j = 0; j < n; j++) {
-                rg[j] = raws[k + j];
-                fg[j] = d->flow(k + j);
-                mg[j] = d->mask(k + j);
-            }
-            D_TRY(mfsr_burst_fuse_rows(d->burst, n, rg, fg, L.flowPitch, mg, L.maskPitch, d->imgOut, d->totalWeights, k == 0 ? 1 : 0,
-                                       mine.rowBegin, mine.rowEnd, (mfsr_stream_t)st));
-        }
-        uint16_t* dst = me == 0 ? out16 : d->out16;
-        // the staging image may still be on its way to rank 0 (gather of the previous burst, on B)
-        if (d->gatherPending) D_HIP(hipStreamWaitEvent(st, d->evGathered, 0));
-        D_TRY(mfsr_burst_finish_rows(d->burst, d->imgOut, d->totalWeights, nullptr, dst, mine.rowBegin, mine.rowEnd - mine.rowBegin,
-                                     (mfsr_stream_t)st));
-    }
-    // gather + status on B after the finish on A; the caller's stream does NOT wait for it (mfsr_dist_wait_output does):
-    // the next burst's alignment runs meanwhile
-    D_HIP(hipEventRecord(d->evFinished, st));
-    D_HIP(hipStreamWaitEvent(B, d->evFinished, 0));
-    if (G > 1) {
-        D_TRY(gather_stripes(d, plan, out16, B));
-        D_TRY(d->T->allReduceMaxI32(flag, B));
-    }
-    if (status) D_HIP(hipMemcpyAsync(status, flag, sizeof(int), hipMemcpyDeviceToDevice, B));
-    D_HIP(hipEventRecord(d->evGathered, B));
-    d->gatherPending = true;
-    return MFSR_OK;
+    if (!d->pipeline) return stripes_back(d, d->cur, d->rawHalo, raws, out16, status, flag, st);
+    // pipelined: now the back half of the PREVIOUS burst (its exchange finished while this burst was being aligned); this
+    // burst's waits for the next call or for mfsr_dist_wait_output.  The caller keeps its frames and out16 until then.
+    const int rc = drain_back(d, st);
+    d->back.has = true;
+    d->back.ctx = d->cur;
+    d->back.rawHalo = d->rawHalo;
+    *d->back.raws = raws;
+    d->back.out16 = out16;
+    d->back.status = status;
+    d->back.flag = flag;
+    return rc;
 }
 
 static int process_reduce(mfsr_dist* d, const uint16_t* const* frames, int mode, uint16_t* out16, int* status, hipStream_t st)
@@ -958,7 +1028,8 @@ extern "C" int mfsr_dist_process_burst(mfsr_dist* d, const uint16_t* const* fram
         if (mode == MFSR_DIST_STRIPES) {
             rc = process_stripes(d, frames, out16, status, st);
         } else {
-            if (d->gatherPending) {  // a STRIPES burst before: its gather uses the transport on the comm stream
+            rc = drain_back(d, st);  // a pipelined STRIPES burst before: its back half first
+            if (rc == MFSR_OK && d->gatherPending) {  // a STRIPES burst before: its gather uses the transport on the comm stream
                 hipError_t e = hipStreamWaitEvent(st, d->evGathered, 0);
                 if (e != hipSuccess) rc = (int)e;
                 d->gatherPending = false;
@@ -973,6 +1044,13 @@ extern "C" int mfsr_dist_process_burst(mfsr_dist* d, const uint16_t* const* fram
 extern "C" int mfsr_dist_wait_output(mfsr_dist* d, mfsr_stream_t stream)
 {
     D_REQUIRE(d != nullptr);
+    // pipelined STRIPES bursts: the last burst's fuse / finish / gather are enqueued here -- transport calls, so every rank
+    // calls this (as it calls process_burst)
+    const int rc = drain_back(d, (hipStream_t)stream);
+    if (rc != MFSR_OK) {
+        if (d->T) d->T->abort();
+        return rc;
+    }
     if (d->gatherPending) D_HIP(hipStreamWaitEvent((hipStream_t)stream, d->evGathered, 0));
     return MFSR_OK;
 }
