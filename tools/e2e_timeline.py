@@ -34,12 +34,18 @@ def run():
 
 
 def summarise(d):
-    kt = glob.glob(d + "/*/*_kernel_trace.csv")[0]
-    mc = glob.glob(d + "/*/*_memory_copy_trace.csv")[0]
-    h = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(mc)) if "HOST_TO_DEVICE" in r["Direction"]][-16:]
+    kt = sorted(glob.glob(d + "/*/*_kernel_trace.csv"), key=os.path.getmtime)[-1]
+    mc = kt.replace("_kernel_trace.csv", "_memory_copy_trace.csv")     # the same process's copy records
+    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Direction"]) for r in csv.DictReader(open(mc))]
+    big = [r for r in rows if r[1] - r[0] > 150_000]                      # frame uploads (0.3 ms) and image bands (0.45 ms)
+    h = [r for r in big if "HOST_TO_DEVICE" in r[2]][-16:]                # the last burst's 16 uploads
     t0 = h[0][0]
     ms = lambda t: (t - t0) / 1e6
     print(f"H2D (last burst): 16 copies, first starts 0.000, last ends {ms(h[-1][1]):.3f} ms, {(h[0][1] - h[0][0]) / 1e6:.3f} ms each")
+    down = [r for r in big if "HOST_TO_DEVICE" not in r[2] and r[0] > t0]  # 2-D device -> host copies (SDMA; listed as D2D / D2H)
+    if down:
+        print(f"D2H (SDMA, 2-D copies): {len(down)} copies, first starts {ms(down[0][0]):.3f}, last ends {ms(down[-1][1]):.3f} ms, "
+              f"{sum(r[1] - r[0] for r in down) / 1e6:.3f} ms busy")
     ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(kt)) if int(r["Start_Timestamp"]) >= t0]
     groups = {}
     for a, b, n in ks:
@@ -48,7 +54,7 @@ def summarise(d):
         g[0], g[1], g[2], g[3] = min(g[0], a), max(g[1], b), g[2] + 1, g[3] + (b - a)
     for n, g in sorted(groups.items(), key=lambda kv: kv[1][0]):
         print(f"  {n:42s} n={g[2]:3d} first start {ms(g[0]):7.3f} last end {ms(g[1]):7.3f} busy {g[3] / 1e6:6.3f} ms")
-    for key in ("k_accumulate2xTile", "k_finishFused", "copy"):
+    for key in ("k_accumulate2xTile", "k_finishFused", "copyBuffer"):
         sel = sorted([k for k in ks if key in k[2]])
         print(f"  {key} (start, end):", [(round(ms(a), 2), round(ms(b), 2)) for a, b, _ in sel])
 

@@ -40,7 +40,7 @@ def main():
         print(f"tie_eps {eps:.1e}: flip {rep['flip_fraction']:.3e}  8-bit >1 outside {rep['n_gt1_8bit_outside']} max8 out {rep['max8_outside']} "
               f"max16 out {rep['max16_outside']} frac16>1 out {rep['frac_gt1_16bit_outside']:.2e}  causes {rep['flips_by_cause_per_frame']}")
     rep = classify(cfg, h, o)
-    print({k: v for k, v in rep.items() if k != "flips_by_cause_per_frame"})
+    print({k: v for k, v in rep.items() if k not in ("flips_by_cause_per_frame", "_flips")})
     E = rep["_flips"]
     out = ~E
     for name in ("img_out", "tw"):
@@ -96,7 +96,8 @@ def main():
     for K0 in (30, 100, 300, 1000, 3000):
         for tau in (0.01, 0.1):
             sel = out[..., None] & (tw >= tau) & (kap[..., None] <= K0)
-            print(f"  kappa <= {K0}, tw >= {tau}: {sel.mean():.4f} of the samples; >1 LSB16: {int((d16[sel] > 1).sum())}, max {int(d16[sel].max())}")
+            if sel.any():
+                print(f"  kappa <= {K0}, tw >= {tau}: {sel.mean():.4f} of the samples; >1 LSB16: {int((d16[sel] > 1).sum())}, max {int(d16[sel].max())}")
     # flow
     for k in range(N):
         if k == cfg.reference:
