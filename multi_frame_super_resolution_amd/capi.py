@@ -57,6 +57,27 @@ class LkFrame(ctypes.Structure):
                 ("sumIn", ctypes.c_void_p), ("diffIn", ctypes.c_void_p), ("sumOut", ctypes.c_void_p), ("diffOut", ctypes.c_void_p)]
 
 
+class PrepareFrame(ctypes.Structure):
+    """mfsr_prepare_frame"""
+    _fields_ = [("dataIn", ctypes.c_void_p), ("halfOut", ctypes.c_void_p), ("pyr0", ctypes.c_void_p), ("pyr1", ctypes.c_void_p)]
+
+
+class TrackFrame(ctypes.Structure):
+    """mfsr_track_frame"""
+    _fields_ = [("movedImg", ctypes.c_void_p), ("coarseShifts", ctypes.c_void_p), ("coordinates", ctypes.c_void_p), ("base", ctypes.c_void_p)]
+
+
+class FlowFieldFrame(ctypes.Structure):
+    """mfsr_flowfield_frame"""
+    _fields_ = [("outImg", ctypes.c_void_p), ("tileShifts", ctypes.c_void_p), ("base", ctypes.c_void_p), ("movedImg", ctypes.c_void_p),
+                ("sumOut", ctypes.c_void_p), ("diffOut", ctypes.c_void_p)]
+
+
+class RobustnessFrame(ctypes.Structure):
+    """mfsr_robustness_frame"""
+    _fields_ = [("movedHalf", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("flow", ctypes.c_void_p)]
+
+
 class Config(ctypes.Structure):
     """mfsr_config (include/mfsr.h)."""
 
