@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(256)
 
     const int shx = round2i(shiftf.x * 0.5f);
     const int shy = round2i(shiftf.y * 0.5f);
+    (void)shx;
 
     pix3 pixelsRef[9];
     float mrx = 0, mry = 0, mrz = 0, mmx = 0, mmy = 0, mmz = 0;
@@ -129,9 +130,15 @@ __global__ void __launch_bounds__(256)
 //    bilinear of the straight kernel and the means are summed in the reference's order and divided exactly;
 //  * reads the one live sample of the 5 x 5 flow loop (x = y = 2, :66) as a plain texel when the flow field has the
 //    image's resolution (the Bayer pipeline): the bilinear fetch lands on a texel centre up to 1 ulp of the coordinate;
-//  * writes the zero ring the reference leaves to its caller (:48-49): no separate ring launch.
+//  * writes the zero ring the reference leaves to its caller (:48-49): no separate ring launch;
+//  * (round 3, RB_FLOW_FIRST) fetches the pixel's flow BEFORE the reference patch is staged and gathers the moved patch
+//    before the barrier: of the three dependent round trips (stage, flow, gather) two overlap -- the kernel waits twice as
+//    long as it issues (SQ_WAIT_INST_ANY 1.05e8 vs SQ_ACTIVE_INST_VALU 5.2e7 per 4-frame launch); 115.5 -> 106 us.
 #define RB_TX 64
 #define RB_TY 8
+#ifndef RB_FLOW_FIRST
+#define RB_FLOW_FIRST 1
+#endif
 template <bool ALIGNED>
 __global__ void __launch_bounds__(RB_TX* RB_TY)
     k_robustnessFused(const pix3* __restrict__ rawImgRef, const pix3* __restrict__ rawImgMoved, float4* __restrict__ robustnessMask,
@@ -146,6 +153,19 @@ __global__ void __launch_bounds__(RB_TX* RB_TY)
     __shared__ float sR[3][RB_TY + 2][RB_TX + 2];
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int x0 = blockIdx.x * RB_TX, y0 = blockIdx.y * RB_TY;
+#if RB_FLOW_FIRST
+    // this pixel's flow first: its fetch and the moved-image gather that depends on it are then in flight while the
+    // reference patch is staged (three dependent round trips become two)
+    const int pxXe = min(x0 + lx, imgWidth - 1), pxYe = min(y0 + ly, imgHeight - 1);
+    const float2 shiftfE =
+        tex2<ADDR_CLAMP>(texUV, ((float)pxXe + 0.5f) / (float)imgWidth, ((float)pxYe + 0.5f) / (float)imgHeight);
+    float2 sE;
+    if (ALIGNED) {
+        sE = row_ptr((const float2*)texUV.ptr, texUV.pitch, min(pxYe + 2, imgHeight - 1))[min(pxXe + 2, imgWidth - 1)];
+    } else {
+        sE = tex2<ADDR_CLAMP>(texUV, ((float)pxXe + (float)2 + 0.5f) / (float)imgWidth, ((float)pxYe + (float)2 + 0.5f) / (float)imgHeight);
+    }
+#endif
     for (int t = ly * RB_TX + lx; t < (RB_TY + 2) * (RB_TX + 2); t += RB_TX * RB_TY) {
         const int r = t / (RB_TX + 2), c = t - r * (RB_TX + 2);
         const int gy = clampi(y0 - 1 + r, 0, imgHeight - 1), gx = clampi(x0 - 1 + c, 0, imgWidth - 1);
@@ -154,6 +174,17 @@ __global__ void __launch_bounds__(RB_TX* RB_TY)
         sR[1][r][c] = p.y;
         sR[2][r][c] = p.z;
     }
+#if RB_FLOW_FIRST
+    // the moved patch under the rounded flow: gathered before the barrier, summed after it
+    const int shxE = round2i(shiftfE.x * 0.5f), shyE = round2i(shiftfE.y * 0.5f);
+    pix3 pmv[9];
+#pragma unroll
+    for (int y = 0; y < 3; y++) {
+        const pix3* rm = row_ptr(rawImgMoved, imgPitch, clampi(pxYe + shyE + y - 1, 0, imgHeight - 1));
+#pragma unroll
+        for (int x = 0; x < 3; x++) pmv[y * 3 + x] = rm[clampi(pxXe + shxE + x - 1, 0, imgWidth - 1)];
+    }
+#endif
     __syncthreads();
     const int pxX = x0 + lx, pxY = y0 + ly;
     if (pxX >= imgWidth || pxY >= imgHeight) return;
@@ -162,6 +193,9 @@ __global__ void __launch_bounds__(RB_TX* RB_TY)
         *out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         return;
     }
+#if RB_FLOW_FIRST
+    const float2 shiftf = shiftfE, s = sE;   // (pxX == pxXe, pxY == pxYe for every pixel that gets here)
+#else
     const float2 shiftf =
         tex2<ADDR_CLAMP>(texUV, ((float)pxX + 0.5f) / (float)imgWidth, ((float)pxY + 0.5f) / (float)imgHeight);
     float2 s;
@@ -170,6 +204,7 @@ __global__ void __launch_bounds__(RB_TX* RB_TY)
     } else {
         s = tex2<ADDR_CLAMP>(texUV, ((float)pxX + (float)2 + 0.5f) / (float)imgWidth, ((float)pxY + (float)2 + 0.5f) / (float)imgHeight);
     }
+#endif
     float2 maxShift, minShift;
     maxShift.x = fmaxf(s.x, shiftf.x);
     maxShift.y = fmaxf(s.y, shiftf.y);
@@ -191,7 +226,12 @@ __global__ void __launch_bounds__(RB_TX* RB_TY)
                 pr[c][y * 3 + x] = sR[c][ly + y][lx + x];
                 mr[c] += pr[c][y * 3 + x];
             }
+#if RB_FLOW_FIRST
+            const pix3 p = pmv[y * 3 + x];
+            (void)rm;
+#else
             const pix3 p = rm[clampi(pxX + shx + x - 1, 0, imgWidth - 1)];
+#endif
             mm[0] += p.x;
             mm[1] += p.y;
             mm[2] += p.z;
