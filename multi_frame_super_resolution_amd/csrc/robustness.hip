@@ -46,7 +46,6 @@ __global__ void __launch_bounds__(256)
 
     const int shx = round2i(shiftf.x * 0.5f);
     const int shy = round2i(shiftf.y * 0.5f);
-    (void)shx;
 
     pix3 pixelsRef[9];
     float mrx = 0, mry = 0, mrz = 0, mmx = 0, mmy = 0, mmz = 0;
@@ -212,6 +211,7 @@ __global__ void __launch_bounds__(RB_TX* RB_TY)
     minShift.y = fminf(s.y, shiftf.y);
     const int shx = round2i(shiftf.x * 0.5f);
     const int shy = round2i(shiftf.y * 0.5f);
+    (void)shx;
 
     // means in the reference's summation order (row-major from 0), exact division by 9
     float pr[3][9];
