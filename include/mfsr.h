@@ -232,6 +232,9 @@ int mfsr_ComputeDerivativesKernel(int width, int height, int stride, float* Ix, 
                                   mfsr_tex2d texSource, mfsr_tex2d texTarget, mfsr_stream_t stream); /* :97 */
 int mfsr_ComputeDerivatives2Kernel(int width, int height, int stride, float* Ix, float* Iy, mfsr_tex2d tex,
                                    mfsr_stream_t stream); /* :151 */
+/* the same for image rows [row0, row0 + rows) only (Ix, Iy are the full-size images) */
+int mfsr_ComputeDerivatives2Rows(int width, int height, int stride, float* Ix, float* Iy, mfsr_tex2d tex, int row0, int rows,
+                                 mfsr_stream_t stream);
 int mfsr_lucasKanadeOptim(mfsr_float2* shifts, const float* imFx, const float* imFy, const float* imFt, int pitchShift,
                           int pitchImg, int width, int height, int halfWindowSize, float minDet,
                           mfsr_stream_t stream); /* :190 */
@@ -518,6 +521,11 @@ void mfsr_burst_destroy(mfsr_burst* b);
 /* Prepare the reference frame (tracking pyramid, half-res RGB, kernel
  * parameters, fallback image).  rawRef: dense u16 width x height on device. */
 int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, mfsr_stream_t stream);
+/* mfsr_burst_set_reference for a burst whose fuse and finish touch HR rows [hrRow0, hrRow1) only (a stripe of a multi-GPU
+ * burst): the products the alignment reads (half-resolution RGB, tracking pyramid, tile sums) are complete, the kernel
+ * parameters and the debayered fallback image are made for the rows that stripe's mfsr_burst_fuse_rows /
+ * mfsr_burst_finish_rows read -- bit-identical there to mfsr_burst_set_reference's, undefined elsewhere. */
+int mfsr_burst_set_reference_rows(mfsr_burst* b, const uint16_t* rawRef, int hrRow0, int hrRow1, mfsr_stream_t stream);
 /* Align + robustness + accumulate ONE frame into the caller's accumulators
  * (float3 HR, pitch 12*scale*width; zeroed by the caller before the first
  * call).  isReference != 0: identity flow, certainty 1.

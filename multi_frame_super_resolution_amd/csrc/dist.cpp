@@ -925,8 +925,14 @@ static int process_stripes(mfsr_dist* d, const uint16_t* const* frames, uint16_t
     hipStream_t B = d->overlap ? d->commStream : st;
     D_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
 
-    // front half: reference products on every rank, then this rank's frames: alignment only
-    D_TRY(mfsr_burst_set_reference(d->ctx(), frames[ref], (mfsr_stream_t)st));
+    // front half: reference products on every rank -- what the alignment reads in full, the kernel parameters and the
+    // fallback image for this rank's stripe only (nobody else reads them here) -- then this rank's frames: alignment only
+    {
+        const mfsr_stripe_plan& mine = plan[me];
+        const bool fuses = mine.rowEnd > mine.rowBegin;
+        D_TRY(mfsr_burst_set_reference_rows(d->ctx(), frames[ref], fuses ? mine.rowBegin : 0, fuses ? mine.rowEnd : (L.hrH < 16 ? L.hrH : 16),
+                                            (mfsr_stream_t)st));
+    }
     std::vector<const uint16_t*> raws(N, nullptr);
     {
         // this rank's frames, aligned in batches (one launch per stage for up to four frames)

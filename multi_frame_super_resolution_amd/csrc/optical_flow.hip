@@ -154,12 +154,13 @@ extern "C" int mfsr_ComputeDerivativesKernel(int width, int height, int stride, 
     return mfsr_launch_status("ComputeDerivativesKernel");
 }
 
+// rows [row0, row0 + rows) of the image only (row0 = 0, rows = height: the whole image)
 __global__ void __launch_bounds__(256) k_ComputeDerivatives2(int width, int height, int stride, float* __restrict__ Ix,
-                                                            float* __restrict__ Iy, mfsr_tex2d tex)
+                                                            float* __restrict__ Iy, mfsr_tex2d tex, int row0, int rows)
 {
     const int ix = threadIdx.x + blockIdx.x * blockDim.x;
-    const int iy = threadIdx.y + blockIdx.y * blockDim.y;
-    if (ix >= width || iy >= height) return;
+    const int iy = row0 + threadIdx.y + blockIdx.y * blockDim.y;
+    if (ix >= width || iy >= row0 + rows || iy >= height) return;
     const float dx = 1.0f / (float)width;
     const float dy = 1.0f / (float)height;
     const float x = ((float)ix + 0.5f) * dx;
@@ -174,8 +175,20 @@ extern "C" int mfsr_ComputeDerivatives2Kernel(int width, int height, int stride,
     MFSR_REQUIRE(Ix && Iy && width > 0 && height > 0 && (long long)stride >= 4LL * width && (stride & 3) == 0);
     MFSR_REQUIRE(mfsr_tex_ok(tex, 4) && tex.width == width && tex.height == height);
     dim3 block(64, 4), grid(mfsr_cdiv(width, 64), mfsr_cdiv(height, 4));
-    hipLaunchKernelGGL(k_ComputeDerivatives2, grid, block, 0, mfsr_s(stream), width, height, stride, Ix, Iy, tex);
+    hipLaunchKernelGGL(k_ComputeDerivatives2, grid, block, 0, mfsr_s(stream), width, height, stride, Ix, Iy, tex, 0, height);
     return mfsr_launch_status("ComputeDerivatives2Kernel");
+}
+
+// the same for image rows [row0, row0 + rows) only (Ix, Iy: the full-size images; other rows are left untouched)
+extern "C" int mfsr_ComputeDerivatives2Rows(int width, int height, int stride, float* Ix, float* Iy, mfsr_tex2d tex, int row0, int rows,
+                                            mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(Ix && Iy && width > 0 && height > 0 && (long long)stride >= 4LL * width && (stride & 3) == 0);
+    MFSR_REQUIRE(mfsr_tex_ok(tex, 4) && tex.width == width && tex.height == height);
+    MFSR_REQUIRE(row0 >= 0 && rows > 0 && row0 + rows <= height);
+    dim3 block(64, 4), grid(mfsr_cdiv(width, 64), mfsr_cdiv(rows, 4));
+    hipLaunchKernelGGL(k_ComputeDerivatives2, grid, block, 0, mfsr_s(stream), width, height, stride, Ix, Iy, tex, row0, rows);
+    return mfsr_launch_status("ComputeDerivatives2Rows");
 }
 
 // ---- D4: lucasKanadeOptim (opticalFlow.cu:190-325) ----------------------------

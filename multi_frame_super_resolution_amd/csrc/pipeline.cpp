@@ -596,12 +596,18 @@ static int prepare_frame(mfsr_burst* b, const uint16_t* raw, Img& half, Img* pyr
     return MFSR_OK;
 }
 
-extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, mfsr_stream_t stream)
+// reference products.  [hrRow0, hrRow1) = the HR rows whose fuse / finish will read the kernel parameters and the fallback image
+// (the whole grid for a single-GPU burst; a stripe for a rank of a multi-GPU burst: those two products are then made for
+// the rows the stripe reads plus the halo their stencils need -- every kernel below works on a row window of the images,
+// so the rows it makes are the bits the whole-image run makes)
+static int set_reference_impl(mfsr_burst* b, const uint16_t* rawRef, int hrRow0, int hrRow1, mfsr_stream_t stream)
 {
     MFSR_REQUIRE(b && rawRef);
     TRY(flush_pending(b, stream, false));  // a frame still waiting belongs to the previous reference
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
+    MFSR_REQUIRE(hrRow0 >= 0 && hrRow1 > hrRow0 && hrRow1 <= L.hrH);
+    const bool whole = (hrRow0 == 0 && hrRow1 == L.hrH) || !c.fused;  // (the unfused chain always makes whole images)
     if (!b->refPrepared) TRY(prepare_frame(b, rawRef, L.refHalf, L.refPyr, stream));
     if (c.fused)
         for (int l = 0; l < c.levels; l++) {
@@ -625,25 +631,47 @@ extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, m
     // fused pipeline also takes the bit-exact two-kernel chain here (+ ~10 us per burst); the derivative images borrow
     // two Lucas-Kanade scratch planes, which no frame of this burst has touched yet.
     {
+        // field rows the fuse of HR rows [hrRow0, hrRow1) samples: floor((Y + .5) * th / hrH - .5) and the next one; the
+        // smoothing reads taps / 2 more on either side (clamped at the IMAGE border only: the window carries that halo)
+        int f0 = 0, f1 = L.th;
+        if (!whole) {
+            const int per = L.hrH / L.th, halo = b->ntensorTaps / 2 + 1;
+            f0 = hrRow0 / per - 1 - halo;
+            f1 = (hrRow1 + per - 1) / per + 1 + halo;
+            f0 = f0 < 0 ? 0 : f0;
+            f1 = f1 > L.th ? L.th : f1;
+        }
+        const int fr = f1 - f0;
         Img& ix = c.fused ? L.lkSum[0] : L.Ix;
         Img& iy = c.fused ? L.lkDiff[0] : L.Iy;
-        TRY(mfsr_ComputeDerivatives2Kernel(L.tw, L.th, ix.pitch, (float*)ix.ptr, (float*)iy.ptr, as_tex(L.refPyr[0]), stream));
-        TRY(mfsr_ComputeStructureTensor((const float*)ix.ptr, (const float*)iy.ptr, (mfsr_float3*)L.tensor.ptr, L.tw, L.th, ix.pitch,
+        auto rows = [&](const Img& im) { return (char*)im.ptr + (size_t)f0 * im.pitch; };
+        TRY(mfsr_ComputeDerivatives2Rows(L.tw, L.th, ix.pitch, (float*)ix.ptr, (float*)iy.ptr, as_tex(L.refPyr[0]), f0, fr, stream));
+        TRY(mfsr_ComputeStructureTensor((const float*)rows(ix), (const float*)rows(iy), (mfsr_float3*)rows(L.tensor), L.tw, fr, ix.pitch,
                                         L.tensor.pitch, stream));
+        TRY(mfsr_separableFilter((const float*)rows(L.tensor), L.tensor.pitch, (float*)rows(L.tensorTmp), (float*)rows(L.tensorSm),
+                                 L.tensorSm.pitch, L.tw, fr, 3, b->tensorTaps, b->ntensorTaps, stream));
+        TRY(mfsr_ComputeKernelParam((mfsr_float3*)rows(L.tensorSm), L.tw, fr, L.tensorSm.pitch, c.Dth, c.Dtr, c.kDetail, c.kDenoise,
+                                    c.kStretch, c.kShrink, stream));
+        TRY(mfsr_float3ToFloat4((const mfsr_float3*)rows(L.tensorSm), L.tensorSm.pitch, (mfsr_float4*)rows(L.kparam4), L.kparam4.pitch,
+                                L.tw, fr, stream));
     }
-    TRY(mfsr_separableFilter((const float*)L.tensor.ptr, L.tensor.pitch, (float*)L.tensorTmp.ptr, (float*)L.tensorSm.ptr,
-                             L.tensorSm.pitch, L.tw, L.th, 3, b->tensorTaps, b->ntensorTaps, stream));
-    TRY(mfsr_ComputeKernelParam((mfsr_float3*)L.tensorSm.ptr, L.tw, L.th, L.tensorSm.pitch, c.Dth, c.Dtr, c.kDetail,
-                                c.kDenoise, c.kStretch, c.kShrink, stream));
-    TRY(mfsr_float3ToFloat4((const mfsr_float3*)L.tensorSm.ptr, L.tensorSm.pitch, (mfsr_float4*)L.kparam4.ptr,
-                            L.kparam4.pitch, L.tw, L.th, stream));
 
-    // A2 + A3: debayered reference = fallback image of ApplyWeighting
+    // A2 + A3: debayered reference = fallback image of ApplyWeighting (finish resamples it bilinearly: raw rows Y / s +- 1;
+    // the row window starts on an even row -- the CFA phase -- and carries the 3-row stencil halo plus the 2-row ring the
+    // kernels leave untouched at a window edge)
     const mfsr_float3 bp = {c.black[0], c.black[1], c.black[2]};
     const mfsr_float3 sc = {1.0f / c.white[0], 1.0f / c.white[1], 1.0f / c.white[2]};
-    MFSR_HIP_TRY(hipMemsetAsync(L.fallback.ptr, 0, (size_t)L.fallback.pitch * L.fallback.h, mfsr_s(stream)));
+    int r0 = 0, r1 = L.H;
+    if (!whole) {
+        r0 = (hrRow0 / c.scale - 8) & ~1;
+        r1 = ((hrRow1 + c.scale - 1) / c.scale + 8 + 1) & ~1;
+        r0 = r0 < 0 ? 0 : r0;
+        r1 = r1 > L.H ? L.H : r1;
+    }
+    char* fb = (char*)L.fallback.ptr + (size_t)r0 * L.fallback.pitch;
+    MFSR_HIP_TRY(hipMemsetAsync(fb, 0, (size_t)L.fallback.pitch * (r1 - r0), mfsr_s(stream)));
     if (c.fused) {
-        TRY(mfsr_deBayerFused(rawRef, (mfsr_float3*)L.fallback.ptr, L.fallback.pitch, L.W, L.H, bp, sc, stream));
+        TRY(mfsr_deBayerFused(rawRef + (size_t)r0 * L.W, (mfsr_float3*)fb, L.fallback.pitch, L.W, r1 - r0, bp, sc, stream));
     } else {
         TRY(mfsr_u16ToFloat(rawRef, (float*)L.rawf.ptr, L.rawf.pitch, L.W, L.H, 1.0f, stream));
         TRY(mfsr_deBayerGreenKernel(L.W, L.H, (const float*)L.rawf.ptr, L.rawf.pitch, (mfsr_float3*)L.fallback.ptr,
@@ -655,6 +683,18 @@ extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, m
     b->refStale = false;
     b->framesSinceRef = 0;
     return MFSR_OK;
+}
+
+extern "C" int mfsr_burst_set_reference(mfsr_burst* b, const uint16_t* rawRef, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b != nullptr);
+    return set_reference_impl(b, rawRef, 0, b->L.hrH, stream);
+}
+
+extern "C" int mfsr_burst_set_reference_rows(mfsr_burst* b, const uint16_t* rawRef, int hrRow0, int hrRow1, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b != nullptr);
+    return set_reference_impl(b, rawRef, hrRow0, hrRow1, stream);
 }
 
 // B: coarse -> fine tile tracking of the moved pyramid against the reference
