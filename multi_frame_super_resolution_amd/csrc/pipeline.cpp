@@ -301,6 +301,10 @@ struct mfsr_burst {
         int isRef[MFSR_MAX_FUSE_GROUP];
         mfsr_float3 *imgOut, *totalWeights;
     } pend;
+    // host bursts: the burst's second-to-last group, aligned and waiting with the last one (pend) for mfsr_burst_finish_host,
+    // which fuses both band by band (heldHas: the entries of `held` are valid)
+    Pending held;
+    bool heldHas;
     int group;  // frames per warp+fuse launch (mfsr_burst_group_size)
     int nFramesTimed;
     // mfsr_burst_begin: these accumulators are to be overwritten by the first fuse instead of zeroed
@@ -480,6 +484,8 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     for (int i = 0; i < 16; i++) b->evBand[i] = nullptr;
     b->framesSinceRef = 0;
     b->holdLastGroup = false;
+    b->heldHas = false;
+    b->held.n = 0;
     b->refHost = b->refDev = nullptr;
     for (int i = 0; i < kMaxUploadRing + 2; i++) {
         b->evUp[i] = b->evFree[i] = nullptr;
@@ -775,8 +781,25 @@ static int upload_slot_of(const mfsr_burst* b, const uint16_t* raw)
 static int align_deferred(mfsr_burst* b, mfsr_stream_t stream);
 
 // G: the waiting group (b->pend, 1 .. MFSR_MAX_FUSE_GROUP aligned frames) onto its accumulators (timed with HIP events on request)
+static int accumulate_pending(mfsr_burst* b, mfsr_stream_t callerStream);
+
+// a group that was held back for mfsr_burst_finish_host and is fused the ordinary way after all (flush / finish / another
+// accumulator pair / its upload slot is needed): as its own launch, exactly as if it had not been held
+static int fuse_held(mfsr_burst* b, mfsr_stream_t callerStream)
+{
+    if (!b->heldHas) return MFSR_OK;
+    const mfsr_burst::Pending later = b->pend;
+    b->pend = b->held;
+    b->heldHas = false;
+    b->held.n = 0;
+    const int rc = accumulate_pending(b, callerStream);
+    b->pend = later;
+    return rc;
+}
+
 static int accumulate_pending(mfsr_burst* b, mfsr_stream_t callerStream)
 {
+    TRY(fuse_held(b, callerStream));       // it comes before the frames that arrived after it
     TRY(align_deferred(b, callerStream));  // frames of the group that were waiting for their batch
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
@@ -861,7 +884,7 @@ static int join_fuse(mfsr_burst* b, mfsr_stream_t stream)
 // fuse the frames still waiting for the rest of their group, then join: afterwards the caller's stream sees every frame
 static int flush_pending(mfsr_burst* b, mfsr_stream_t stream, bool materializeFresh)
 {
-    if (materializeFresh && b->fresh.has && b->pend.n == 0) {
+    if (materializeFresh && b->fresh.has && b->pend.n == 0 && !b->heldHas) {
         // mfsr_burst_begin with no frame fused since: the accumulators must read as zero
         const size_t bytes = (size_t)12 * b->L.hrW * b->L.hrH;
         MFSR_HIP_TRY(hipMemsetAsync(b->fresh.imgOut, 0, bytes, mfsr_s(stream)));
@@ -1261,6 +1284,24 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
     // host bursts: the group that the burst's last frame completes is fused band by band by mfsr_burst_finish_host, so that
     // finished bands of the image leave for the host while the later ones are still being fused
     if (b->holdLastGroup && b->framesSinceRef >= c.frames) return MFSR_OK;
+    // ... and so does the group before it (MFSR_HOST_HOLD=2, the default): the first band of the image is then complete after
+    // 1/8 of two groups' fuse instead of after a whole group's, and the download -- the tail of the burst -- starts that much
+    // earlier; the earlier groups are fused as they arrive, under the uploads
+    static const int holdGroups = [] {
+        const char* e = getenv("MFSR_HOST_HOLD");
+        return e ? atoi(e) : 2;
+    }();
+    if (b->holdLastGroup && holdGroups >= 2 && !b->heldHas && c.frames - b->framesSinceRef <= b->group &&
+        c.frames - b->framesSinceRef > 0 && !b->pend.deferred[0]) {
+        bool aligned = true;
+        for (int j = 0; j < b->pend.n; j++) aligned = aligned && !b->pend.deferred[j];
+        if (aligned) {
+            b->held = b->pend;
+            b->heldHas = true;
+            b->pend.n = 0;
+            return MFSR_OK;
+        }
+    }
     return accumulate_pending(b, stream);
 }
 
@@ -1540,11 +1581,13 @@ extern "C" int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw,
         return mfsr_burst_add_frame(b, b->refDev, 1, imgOut, totalWeights, stream);
     const int us = b->upCounter++ % b->cfg.uploadRing;
     // a ring shorter than the fuse group: the slot may still hold a frame that waits for the rest of its group
-    for (int i = 0; i < b->pend.n; i++)
-        if (b->pend.raw[i] == b->L.rawRing[us]) {
-            TRY(accumulate_pending(b, stream));
-            break;
-        }
+    bool waiting = false, waitingHeld = false;
+    for (int i = 0; i < b->pend.n; i++) waiting = waiting || b->pend.raw[i] == b->L.rawRing[us];
+    for (int i = 0; b->heldHas && i < b->held.n; i++) waitingHeld = waitingHeld || b->held.raw[i] == b->L.rawRing[us];
+    if (waiting)
+        TRY(accumulate_pending(b, stream));
+    else if (waitingHeld)
+        TRY(fuse_held(b, stream));  // only the held group: the frames waiting after it keep their group
     TRY(upload_into(b, us, b->L.rawRing[us], hostRaw, stream));
     return mfsr_burst_add_frame(b, b->L.rawRing[us], isReference, imgOut, totalWeights, stream);
 }
@@ -1574,7 +1617,11 @@ extern "C" int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, 
         return e ? atoi(e) : 8;
     }();
     int nBands = nBandsEnv < 1 ? 1 : (nBandsEnv > 16 ? 16 : nBandsEnv);
-    const bool heldGroup = b->pend.n > 0 && b->pend.imgOut == imgOut && b->pend.totalWeights == totalWeights && c.fused;
+    bool heldGroup = b->pend.n > 0 && b->pend.imgOut == imgOut && b->pend.totalWeights == totalWeights && c.fused;
+    if (b->heldHas && !(heldGroup && b->held.imgOut == imgOut && b->held.totalWeights == totalWeights)) {
+        TRY(flush_pending(b, stream));  // a held group without the last one, or other accumulators: the ordinary way
+        heldGroup = false;
+    }
     if (!heldGroup) TRY(flush_pending(b, stream));  // (another accumulator pair, or the unfused chain: nothing to pipeline)
     const size_t rowBytes = (size_t)L.hrW * 6;
     if (nBands == 1 && !heldGroup) {
@@ -1587,12 +1634,18 @@ extern "C" int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, 
         b->downRecorded = true;
         return MFSR_OK;
     }
-    mfsr_burst::Pending p = b->pend;
+    mfsr_burst::Pending p = b->pend, p0;
+    p0.n = 0;
     int freshNow = 0;
     if (heldGroup) {
         TRY(align_deferred(b, stream));
         p = b->pend;
         b->pend.n = 0;
+        if (b->heldHas) {
+            p0 = b->held;  // the second-to-last group: fused first on every band (frame order)
+            b->heldHas = false;
+            b->held.n = 0;
+        }
         TRY(join_fuse(b, stream));  // the earlier groups' launches ran on the burst's own stream
         freshNow = b->fresh.has && b->fresh.imgOut == imgOut && b->fresh.totalWeights == totalWeights;
         if (b->fresh.has && !freshNow) {
@@ -1612,15 +1665,22 @@ extern "C" int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, 
         if (r1 > L.hrH || i == nBands - 1) r1 = L.hrH;
         if (r1 <= r0) continue;
         if (heldGroup) {
-            const mfsr_float4* masks[MFSR_MAX_FUSE_GROUP];
-            mfsr_tex2d flows[MFSR_MAX_FUSE_GROUP];
-            for (int k = 0; k < p.n; k++) {
-                masks[k] = (const mfsr_float4*)p.mask[k]->ptr;
-                flows[k] = as_tex(*p.flow[k]);
+            const mfsr_burst::Pending* gs[2] = {&p0, &p};
+            int fresh = freshNow;
+            for (int gi = 0; gi < 2; gi++) {
+                const mfsr_burst::Pending& q = *gs[gi];
+                if (q.n == 0) continue;
+                const mfsr_float4* masks[MFSR_MAX_FUSE_GROUP];
+                mfsr_tex2d flows[MFSR_MAX_FUSE_GROUP];
+                for (int k = 0; k < q.n; k++) {
+                    masks[k] = (const mfsr_float4*)q.mask[k]->ptr;
+                    flows[k] = as_tex(*q.flow[k]);
+                }
+                TRY(mfsr_accumulateSuperResFullRows(q.n, q.raw, const_cast<mfsr_float3*>(imgOut), const_cast<mfsr_float3*>(totalWeights),
+                                                    masks, as_tex(L.kparam4), flows, white, black, L.W, L.H, c.scale, 12 * L.hrW,
+                                                    q.mask[0]->pitch, fresh, r0, r1, stream));
+                fresh = 0;
             }
-            TRY(mfsr_accumulateSuperResFullRows(p.n, p.raw, const_cast<mfsr_float3*>(imgOut), const_cast<mfsr_float3*>(totalWeights),
-                                                masks, as_tex(L.kparam4), flows, white, black, L.W, L.H, c.scale, 12 * L.hrW,
-                                                p.mask[0]->pitch, freshNow, r0, r1, stream));
         }
         const size_t off = (size_t)r0 * 12 * L.hrW;
         TRY(mfsr_finishFusedRows((const mfsr_float3*)((const char*)imgOut + off), (const mfsr_float3*)((const char*)totalWeights + off),
@@ -1635,11 +1695,14 @@ extern "C" int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, 
     }
     if (heldGroup && b->copyStream) {
         // upload slots whose raw frame these launches were the last to read
-        for (int j = 0; j < p.n; j++) {
-            const int us = upload_slot_of(b, p.raw[j]);
-            if (us >= 0) {
-                MFSR_HIP_TRY(hipEventRecord(b->evFree[us], mfsr_s(stream)));
-                b->freeRecorded[us] = true;
+        for (int gi = 0; gi < 2; gi++) {
+            const mfsr_burst::Pending& q = gi ? p : p0;
+            for (int j = 0; j < q.n; j++) {
+                const int us = upload_slot_of(b, q.raw[j]);
+                if (us >= 0) {
+                    MFSR_HIP_TRY(hipEventRecord(b->evFree[us], mfsr_s(stream)));
+                    b->freeRecorded[us] = true;
+                }
             }
         }
     }
