@@ -187,6 +187,37 @@ __device__ __forceinline__ void tap_weights13(float kx, float ky, float kz, floa
     w[12] = 1.0f;
 }
 
+// tail of a strip pixel: C[jt][i] = sum over the taps of tap row jt on site column i of weight x certainty -> the nine
+// site weights (tap rows 1 and 3 change site row with the y parity bit), class sums, channels
+template <int K, int CFA>
+__device__ __forceinline__ void strip_pixel_sites(const float (&C)[5][3], const float (&s)[3][3], uint32_t mby, uint32_t nby, uint32_t mP,
+                                                   uint32_t mQ, const StripLevels& lv, float* accP, float* accW)
+{
+    auto andm = [](uint32_t m, float a) { return __uint_as_float(m & __float_as_uint(a)); };
+    // site rows: tap row 0, row 1 if by == 0 | row 1 if by == 1, row 2, row 3 if by == 0 | row 3 if by == 1, row 4
+    float Om[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        Om[0][i] = C[0][i] + andm(nby, C[1][i]);
+        // (C1 & by) + C2 + (C3 & ~by) with one of the two masked terms zero: C2 + (by ? C1 : C3), the same sum (the terms
+        // are non-negative, x + 0 is exact) in two instructions instead of four
+        Om[1][i] = C[2][i] + selm(mby, C[1][i], C[3][i]);
+        Om[2][i] = andm(mby, C[3][i]) + C[4][i];
+    }
+    // class (yc, xc) = (j & 1, i & 1), relative to (Q, P)
+    float S[2][2], W[2][2];
+    S[0][0] = __builtin_fmaf(s[2][2], Om[2][2], __builtin_fmaf(s[2][0], Om[2][0], __builtin_fmaf(s[0][2], Om[0][2], s[0][0] * Om[0][0])));
+    W[0][0] = (Om[0][0] + Om[0][2]) + (Om[2][0] + Om[2][2]);
+    S[0][1] = __builtin_fmaf(s[2][1], Om[2][1], s[0][1] * Om[0][1]);
+    W[0][1] = Om[0][1] + Om[2][1];
+    S[1][0] = __builtin_fmaf(s[1][2], Om[1][2], s[1][0] * Om[1][0]);
+    W[1][0] = Om[1][0] + Om[1][2];
+    S[1][1] = s[1][1] * Om[1][1];
+    W[1][1] = Om[1][1];
+
+    classes_to_channels<K, CFA>(S, W, mP, mQ, lv, accP, accW);
+}
+
 // Second formulation of the same pixel: the dynamic part (which raw site a tap lands on) is
 // applied to the WEIGHTS, not to the values.
 //  * site sums: out = sum_sites raw[j][i] * Om[j][i], Om[j][i] = sum of w*certainty over the taps on
@@ -292,26 +323,52 @@ __device__ __forceinline__ void strip_pixel_w(int X, int Y, int sx, int sy, cons
         C[jt][2] = cidx(3) == cidx(4) ? (WH(jt, 3) + W_(jt, 4)) * Ee[cidx(3)]
                                       : __builtin_fmaf(W_(jt, 4), Ee[cidx(4)], WH(jt, 3) * Ee[cidx(3)]);
     }
-    // site rows: tap row 0, row 1 if by == 0 | row 1 if by == 1, row 2, row 3 if by == 0 | row 3 if by == 1, row 4
-    float Om[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        Om[0][i] = C[0][i] + andm(nby, C[1][i]);
-        Om[1][i] = (andm(mby, C[1][i]) + C[2][i]) + andm(nby, C[3][i]);
-        Om[2][i] = andm(mby, C[3][i]) + C[4][i];
-    }
-    // class (yc, xc) = (j & 1, i & 1), relative to (Q, P)
-    float S[2][2], W[2][2];
-    S[0][0] = __builtin_fmaf(s[2][2], Om[2][2], __builtin_fmaf(s[2][0], Om[2][0], __builtin_fmaf(s[0][2], Om[0][2], s[0][0] * Om[0][0])));
-    W[0][0] = (Om[0][0] + Om[0][2]) + (Om[2][0] + Om[2][2]);
-    S[0][1] = __builtin_fmaf(s[2][1], Om[2][1], s[0][1] * Om[0][1]);
-    W[0][1] = Om[0][1] + Om[2][1];
-    S[1][0] = __builtin_fmaf(s[1][2], Om[1][2], s[1][0] * Om[1][0]);
-    W[1][0] = Om[1][0] + Om[1][2];
-    S[1][1] = s[1][1] * Om[1][1];
-    W[1][1] = Om[1][1];
+    strip_pixel_sites<K, CFA>(C, s, mby, nby, mP, mQ, lv, accP, accW);
+}
 
-    classes_to_channels<K, CFA>(S, W, mP, mQ, lv, accP, accW);
+// The same pixel where every certainty texel its wave touches is exactly 1 in every channel (the robustness mask
+// saturates at 1 over well-aligned content: most of a typical frame).  strip_pixel_w with Ee = Eo = 1 folded: the
+// products with the certainty are exact no-ops, so the column sums of a tap row are sums of WEIGHTS that depend on the
+// frame through the x parity bit only -- one select per site column between two sums the caller makes once per pixel
+// for all frames (P[r][0..3] = W0+W1, W1+W2, W2+W3, W3+W4 of tap row r = 0, 1, 2; rows 3 and 4 mirror rows 1 and 0).
+// No certainty reads, no certainty addresses, 15 selects instead of 45 and/add/mul/fma: bit-identical to strip_pixel_w
+// on such a pixel (same sums in the same association; x + 0 and x * 1 are exact).
+template <int K, int CFA, typename RawF>
+__device__ __forceinline__ void strip_pixel_sat(int X, int Y, int sx, int sy, const float (&w)[13], const float (&P)[3][4], RawF rawf,
+                                                 const StripLevels& lv, float* accP, float* accW)
+{
+    const int qx = X + sx - 2, qy = Y + sy - 2;
+    const int x0 = qx >> 1, y0 = qy >> 1;
+    uint32_t mbx = 0u - (uint32_t)(qx & 1), mby = 0u - (uint32_t)(qy & 1);
+    uint32_t nby = ~mby;
+    asm volatile("" : "+v"(mbx), "+v"(mby), "+v"(nby));
+    const uint32_t mP = 0u - (uint32_t)(x0 & 1), mQ = 0u - (uint32_t)(y0 & 1);
+    float s[3][3];
+    rawf(x0, y0, s);
+    float C[5][3];
+#pragma unroll
+    for (int jt = 0; jt < 5; jt++) {
+        // tap row jt = row r read forwards (jt <= 2) or backwards (jt >= 3: w[n] == w[24 - n])
+        const int r = jt <= 2 ? jt : 4 - jt;
+        const bool rev = jt >= 3;
+        const float W0 = w[5 * r + (rev ? 4 : 0) <= 12 ? 5 * r + (rev ? 4 : 0) : 24 - (5 * r + (rev ? 4 : 0))];
+        const float W4 = w[5 * r + (rev ? 0 : 4) <= 12 ? 5 * r + (rev ? 0 : 4) : 24 - (5 * r + (rev ? 0 : 4))];
+        const float P01 = P[r][rev ? 3 : 0], P12 = P[r][rev ? 2 : 1], P23 = P[r][rev ? 1 : 2], P34 = P[r][rev ? 0 : 3];
+        C[jt][0] = selm(mbx, W0, P01);   // tap 0, tap 1 if bx == 0
+        C[jt][1] = selm(mbx, P12, P23);  // tap 1 if bx == 1, tap 2, tap 3 if bx == 0
+        C[jt][2] = selm(mbx, P34, W4);   // tap 3 if bx == 1, tap 4
+    }
+    strip_pixel_sites<K, CFA>(C, s, mby, nby, mP, mQ, lv, accP, accW);
+}
+
+// P[r][i] = W(r, i) + W(r, i + 1) of tap rows 0..2, in the association strip_pixel_w uses (see strip_pixel_sat)
+__device__ __forceinline__ void tap_pair_sums(const float (&w)[13], float (&P)[3][4])
+{
+    auto W_ = [&](int jt, int it) { const int n = jt * 5 + it; return w[n <= 12 ? n : 24 - n]; };
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) P[r][i] = W_(r, i) + W_(r, i + 1);
 }
 
 template <int K, int CFA, bool PARITY = false, typename MaskF>
@@ -655,6 +712,12 @@ __global__ void __launch_bounds__(256)
 #ifndef TILE_PIXEL_MAJOR
 #define TILE_PIXEL_MAJOR 1
 #endif
+// pixel-major loop: frames whose certainty is saturated over the wave's footprint take strip_pixel_sat (0: A/B)
+#ifndef TILE_SAT_PATH
+#define TILE_SAT_PATH 1
+#endif
+// (Measured and not kept: the nine raw sites of a body loaded one body ahead -- 161 VGPRs, the address arithmetic twice:
+// 0.96 against 0.876 ms per isolated launch.  The round trip of the raw loads is already hidden.)
 // NF frames per launch (1 to 4).  Everything that does not depend on the frame is done once for
 // both: the accumulator staging and write-back (the 48 B/px/frame of HBM traffic become 24), the
 // kernel-parameter mix, the column/row fractions.  The two frames add into the same registers.
@@ -683,6 +746,7 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
     __shared__ float4 sK[FROWS][FC];  // .w = 1 if the texel is PSD and finite, else 0
     __shared__ float2 sF[NF][FROWS][FC];
     __shared__ float4 sM[NF][3][TILE_COLS];
+    __shared__ uint32_t sUnsat[3][TILE_COLS];  // bit n: frame n's certainty texel is not (1, 1, 1)  (TILE_SAT_PATH)
     __shared__ __attribute__((aligned(16))) float sColA[256];  // x fraction per HR column of the tile, -1 = not on the predicted texel
     __shared__ float sRowB[4];                                 // y fraction per HR row of the tile, -1 likewise
     // accumulator staging: per wave and plane-set the wave's 3 KiB row segment, in memory order
@@ -714,13 +778,16 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
             if (t < 3 * TILE_COLS) {
                 const int r = t / TILE_COLS, c = t - r * TILE_COLS;
                 const int gy = bIdY - 1 + r, gx = bIdX * 64 - 1 + c;
+                uint32_t unsat = 0;
 #pragma unroll
                 for (int n = 0; n < NF; n++) {
                     const float4 m = row_ptr(fr.f[n].mask, strideMask, clampi(gy, 0, mh - 1))[clampi(gx, 0, mw - 1)];
                     const float mc[3] = {sane(m.x), sane(m.y), sane(m.z)};
                     sM[n][r][c] = make_float4(mc[Cfa<CFA>::col(0, 0)], mc[Cfa<CFA>::col(0, 1)], mc[Cfa<CFA>::col(1, 0)],
                                               mc[Cfa<CFA>::col(1, 1)]);
+                    if (!(mc[0] == 1.0f && mc[1] == 1.0f && mc[2] == 1.0f)) unsat |= 1u << n;
                 }
+                sUnsat[r][c] = unsat;
             }
         } else if (t < 3 * TILE_COLS) {
             const int r = t / TILE_COLS, c = t - r * TILE_COLS;
@@ -730,6 +797,7 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
             // a bilinear mix of PSD matrices is PSD, so admitting texels admits every pixel between them
             k.w = psd_ok(k.x, k.y, k.z) ? 1.0f : 0.0f;
             sK[r][c] = k;
+            uint32_t unsat = 0;
 #pragma unroll
             for (int n = 0; n < NF; n++) {
                 sF[n][r][c] = row_ptr((const float2*)fr.f[n].shifts.ptr, fr.f[n].shifts.pitch, fy)[fx];
@@ -738,7 +806,9 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
                 const float mc[3] = {sane(m.x), sane(m.y), sane(m.z)};
                 sM[n][r][c] = make_float4(mc[Cfa<CFA>::col(0, 0)], mc[Cfa<CFA>::col(0, 1)], mc[Cfa<CFA>::col(1, 0)],
                                           mc[Cfa<CFA>::col(1, 1)]);
+                if (!(mc[0] == 1.0f && mc[1] == 1.0f && mc[2] == 1.0f)) unsat |= 1u << n;
             }
+            sUnsat[r][c] = unsat;
         }
         {
             // column t of the tile: the float path of tex_coord, texel column predicted and verified
@@ -874,6 +944,18 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
         for (int n = 0; n < NF; n++)
 #pragma unroll
             for (int j = 0; j < 3; j++) rawRow[n][j] = (const char*)(fr.f[n].raw + (size_t)j * dimX);
+        // Frames whose certainty is exactly 1 on every texel this WAVE reads (its 66 texel columns on the two mask rows
+        // its tap rows touch) take strip_pixel_sat: a wave-uniform (scalar) branch per frame, bit-identical results.
+        uint32_t satW = 0;
+        if constexpr (TILE_SAT_PATH) {
+            const int r0 = ((ly - 2) >> 2) + 1;  // mask rows ((ly + jt - 2) >> 2) + 1, jt = 0..4: r0 and r0 + 1
+            uint32_t u = sUnsat[r0][lx] | sUnsat[r0 + 1][lx];
+            if (lx < 2) u |= sUnsat[r0][64 + lx] | sUnsat[r0 + 1][64 + lx];
+#pragma unroll
+            for (int n = 0; n < NF; n++)
+                if (__builtin_amdgcn_ballot_w64((u >> n) & 1u) == 0) satW |= 1u << n;
+            satW = (uint32_t)__builtin_amdgcn_readfirstlane((int)satW);
+        }
         auto pixel = [&](auto kc) {
             constexpr int k = decltype(kc)::value;
             if (safeBits == 0) return;
@@ -883,6 +965,8 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
             aP[3 * k] = aP[3 * k + 1] = aP[3 * k + 2] = 0.0f;
             float w[13];
             tap_weights13(kxa[k], kya[k], kza[k], w);
+            float P[3][4];
+            if (TILE_SAT_PATH && satW) tap_pair_sums(w, P);
 #pragma unroll
             for (int n = 0; n < NF; n++) {
                 if ((safeBits >> n) & 1u) {
@@ -899,7 +983,10 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
                         return *(const float*)((const char*)(mrow[jt] + n * (3 * TILE_COLS * 4) + cell * 4) + e4);
                     };
                     const int sx = (int)(int16_t)(sxy[n][k] & 0xffffu), sy = (int)sxy[n][k] >> 16;
-                    strip_pixel_w<k, CFA, true>(X0 + k, Y, sx, sy, w, rawf, mval, lv, aP, accW);
+                    if (TILE_SAT_PATH && ((satW >> n) & 1u))
+                        strip_pixel_sat<k, CFA>(X0 + k, Y, sx, sy, w, P, rawf, lv, aP, accW);
+                    else
+                        strip_pixel_w<k, CFA, true>(X0 + k, Y, sx, sy, w, rawf, mval, lv, aP, accW);
                 }
             }
             if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged plane-set has landed (long ago)

@@ -204,10 +204,10 @@ void make_layout(const mfsr_config* c, char* base, Layout* L)
             L->lkDiff[i] = b.image(L->tw, L->th, 4);
         }
     }
+    L->Ix = b.image(L->tw, L->th, 4);  // (fused: the derivative images of the kernel-parameter chain, made on the fuse stream)
+    L->Iy = b.image(L->tw, L->th, 4);
     if (!c->fused) {
         L->warped = b.image(L->tw, L->th, 4);
-        L->Ix = b.image(L->tw, L->th, 4);
-        L->Iy = b.image(L->tw, L->th, 4);
         L->It = b.image(L->tw, L->th, 4);
         L->rawf = b.image(L->W, L->H, 4);
         L->refTiles = (float*)b.take(maxTileFloats * 4);
@@ -317,6 +317,10 @@ struct mfsr_burst {
     hipStream_t fuseStream;             // high priority, non-blocking; null without asyncFuse
     hipEvent_t evAligned[kRing];        // recorded on the caller's stream when slot's flow/mask are complete
     hipEvent_t evFused[kRing];          // recorded on fuseStream when the fuse that read the slot is done
+    // the reference products only the fuse and the finish read (kernel parameters, debayered fallback image) are made on
+    // fuseStream, beside the alignment of the first group on the caller's stream: off the critical path of the burst
+    hipEvent_t evRefStart, evRefDone;
+    bool refOnFuse;                     // evRefDone is pending for consumers on other streams than fuseStream
     bool fusedOutstanding[kRing];       // evFused[slot] recorded and not yet waited for by the caller's stream
     Img* slotFlow[kRing];               // which buffer of the slot's LK ping-pong pair holds the frame's final flow
     // host-frame bursts (cfg.uploadRing): copy stream, per-slot events, reference double buffer
@@ -330,6 +334,7 @@ struct mfsr_burst {
     hipEvent_t evUp[kMaxUploadRing + 2];    // upload of the slot complete (copy stream); [ring..ring+1] = reference slots
     hipEvent_t evFree[kMaxUploadRing + 2];  // last consumer of the slot enqueued (compute / fuse stream)
     bool freeRecorded[kMaxUploadRing + 2];
+    int refSlot;                            // upload slot of the current host reference (-1: none / released)
     int upCounter, refCounter;
     const uint16_t* refHost;                // host pointer of the current reference and its device copy
     const uint16_t* refDev;
@@ -457,6 +462,8 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     memset(b->evStop, 0, sizeof(b->evStop));
     b->frameCounter = 0;
     b->fuseStream = nullptr;
+    b->evRefStart = b->evRefDone = nullptr;
+    b->refOnFuse = false;
     for (int i = 0; i < kRing; i++) {
         b->evAligned[i] = b->evFused[i] = nullptr;
         b->fusedOutstanding[i] = false;
@@ -465,6 +472,8 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
         int lo = 0, hi = 0;
         hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->fuseStream, hipStreamNonBlocking, hi);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evRefStart, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evRefDone, hipEventDisableTiming);
         for (int i = 0; i < kRing && e == hipSuccess; i++) {
             e = hipEventCreateWithFlags(&b->evAligned[i], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evFused[i], hipEventDisableTiming);
@@ -490,6 +499,7 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     for (int i = 0; i < kMaxUploadRing + 2; i++) {
         b->evUp[i] = b->evFree[i] = nullptr;
         b->freeRecorded[i] = false;
+        b->refSlot = -1;
     }
     if (cfg->uploadRing > 0) {
         hipError_t e = hipStreamCreateWithFlags(&b->copyStream, hipStreamNonBlocking);
@@ -523,6 +533,8 @@ extern "C" void mfsr_burst_destroy(mfsr_burst* b)
         if (b->evAligned[i]) (void)hipEventDestroy(b->evAligned[i]);
         if (b->evFused[i]) (void)hipEventDestroy(b->evFused[i]);
     }
+    if (b->evRefStart) (void)hipEventDestroy(b->evRefStart);
+    if (b->evRefDone) (void)hipEventDestroy(b->evRefDone);
     if (b->fuseStream) (void)hipStreamDestroy(b->fuseStream);
     if (b->copyStream) (void)hipStreamSynchronize(b->copyStream);
     if (b->downStream) (void)hipStreamSynchronize(b->downStream);
@@ -628,14 +640,28 @@ static int set_reference_impl(mfsr_burst* b, const uint16_t* rawRef, int hrRow0,
             TRY(mfsr_preAlignPyramid((const float*)L.refPyr[0].ptr, L.tw, L.th, L.refPyr[0].pitch, L.preRefPyr, stream));
     }
 
+    // What follows is read by the fuse and the finish only, not by the alignment: with cfg.asyncFuse it runs on the burst's fuse
+    // stream (after everything the caller's stream has enqueued so far: the previous burst's finish reads the same images),
+    // beside the alignment of the first group -- 0.2 ms off the burst's critical path, on which the GPU is otherwise
+    // half empty.  MFSR_REF_OVERLAP=0: on the caller's stream (A/B).
+    static const bool refOverlap = [] {
+        const char* e = getenv("MFSR_REF_OVERLAP");
+        return !(e && e[0] == '0');
+    }();
+    mfsr_stream_t es = stream;
+    b->refOnFuse = false;
+    if (refOverlap && b->fuseStream && c.fused) {
+        MFSR_HIP_TRY(hipEventRecord(b->evRefStart, mfsr_s(stream)));
+        MFSR_HIP_TRY(hipStreamWaitEvent(b->fuseStream, b->evRefStart, 0));
+        es = (mfsr_stream_t)b->fuseStream;
+    }
     // E: kernel shape field from the reference tracking image
     // E1 + E2 run once per burst on an LR-sized image, and E3 turns their result into the kernel ORIENTATION through an
     // eigen-decomposition that is ill-conditioned wherever the tensor is nearly isotropic (k1 != k2 even there,
     // kernel.cu:766-772): a tensor that differs in its last bits (mfsr_structureTensorFused reads the texels directly
     // instead of blending them with the ~1e-7 weights an exact-float bilinear fetch at a texel centre has) moves the tap
     // exponents by up to 0.5 there, i.e. the accumulators by 1e-3 relative -- measured, tools/parity_audit.py.  So the
-    // fused pipeline also takes the bit-exact two-kernel chain here (+ ~10 us per burst); the derivative images borrow
-    // two Lucas-Kanade scratch planes, which no frame of this burst has touched yet.
+    // fused pipeline also takes the bit-exact two-kernel chain here (+ ~10 us per burst).
     {
         // field rows the fuse of HR rows [hrRow0, hrRow1) samples: floor((Y + .5) * th / hrH - .5) and the next one; the
         // smoothing reads taps / 2 more on either side (clamped at the IMAGE border only: the window carries that halo)
@@ -648,18 +674,18 @@ static int set_reference_impl(mfsr_burst* b, const uint16_t* rawRef, int hrRow0,
             f1 = f1 > L.th ? L.th : f1;
         }
         const int fr = f1 - f0;
-        Img& ix = c.fused ? L.lkSum[0] : L.Ix;
-        Img& iy = c.fused ? L.lkDiff[0] : L.Iy;
+        Img& ix = L.Ix;
+        Img& iy = L.Iy;
         auto rows = [&](const Img& im) { return (char*)im.ptr + (size_t)f0 * im.pitch; };
-        TRY(mfsr_ComputeDerivatives2Rows(L.tw, L.th, ix.pitch, (float*)ix.ptr, (float*)iy.ptr, as_tex(L.refPyr[0]), f0, fr, stream));
+        TRY(mfsr_ComputeDerivatives2Rows(L.tw, L.th, ix.pitch, (float*)ix.ptr, (float*)iy.ptr, as_tex(L.refPyr[0]), f0, fr, es));
         TRY(mfsr_ComputeStructureTensor((const float*)rows(ix), (const float*)rows(iy), (mfsr_float3*)rows(L.tensor), L.tw, fr, ix.pitch,
-                                        L.tensor.pitch, stream));
+                                        L.tensor.pitch, es));
         TRY(mfsr_separableFilter((const float*)rows(L.tensor), L.tensor.pitch, (float*)rows(L.tensorTmp), (float*)rows(L.tensorSm),
-                                 L.tensorSm.pitch, L.tw, fr, 3, b->tensorTaps, b->ntensorTaps, stream));
+                                 L.tensorSm.pitch, L.tw, fr, 3, b->tensorTaps, b->ntensorTaps, es));
         TRY(mfsr_ComputeKernelParam((mfsr_float3*)rows(L.tensorSm), L.tw, fr, L.tensorSm.pitch, c.Dth, c.Dtr, c.kDetail, c.kDenoise,
-                                    c.kStretch, c.kShrink, stream));
+                                    c.kStretch, c.kShrink, es));
         TRY(mfsr_float3ToFloat4((const mfsr_float3*)rows(L.tensorSm), L.tensorSm.pitch, (mfsr_float4*)rows(L.kparam4), L.kparam4.pitch,
-                                L.tw, fr, stream));
+                                L.tw, fr, es));
     }
 
     // A2 + A3: debayered reference = fallback image of ApplyWeighting (finish resamples it bilinearly: raw rows Y / s +- 1;
@@ -675,9 +701,13 @@ static int set_reference_impl(mfsr_burst* b, const uint16_t* rawRef, int hrRow0,
         r1 = r1 > L.H ? L.H : r1;
     }
     char* fb = (char*)L.fallback.ptr + (size_t)r0 * L.fallback.pitch;
-    MFSR_HIP_TRY(hipMemsetAsync(fb, 0, (size_t)L.fallback.pitch * (r1 - r0), mfsr_s(stream)));
+    MFSR_HIP_TRY(hipMemsetAsync(fb, 0, (size_t)L.fallback.pitch * (r1 - r0), mfsr_s(es)));
     if (c.fused) {
-        TRY(mfsr_deBayerFused(rawRef + (size_t)r0 * L.W, (mfsr_float3*)fb, L.fallback.pitch, L.W, r1 - r0, bp, sc, stream));
+        TRY(mfsr_deBayerFused(rawRef + (size_t)r0 * L.W, (mfsr_float3*)fb, L.fallback.pitch, L.W, r1 - r0, bp, sc, es));
+        if (es != stream) {
+            MFSR_HIP_TRY(hipEventRecord(b->evRefDone, b->fuseStream));
+            b->refOnFuse = true;
+        }
     } else {
         TRY(mfsr_u16ToFloat(rawRef, (float*)L.rawf.ptr, L.rawf.pitch, L.W, L.H, 1.0f, stream));
         TRY(mfsr_deBayerGreenKernel(L.W, L.H, (const float*)L.rawf.ptr, L.rawf.pitch, (mfsr_float3*)L.fallback.ptr,
@@ -869,10 +899,18 @@ static int accumulate_pending(mfsr_burst* b, mfsr_stream_t callerStream)
     return MFSR_OK;
 }
 
-// the caller's stream waits for every fuse issued so far (no-op without asyncFuse)
+// `stream` is about to read the kernel parameters / the fallback image: wait for the launches that make them
+static int wait_ref_products(mfsr_burst* b, mfsr_stream_t stream)
+{
+    if (b->refOnFuse && mfsr_s(stream) != b->fuseStream) MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evRefDone, 0));
+    return MFSR_OK;
+}
+
+// the caller's stream waits for every fuse issued so far, and for the reference products (no-op without asyncFuse)
 static int join_fuse(mfsr_burst* b, mfsr_stream_t stream)
 {
     if (!b->fuseStream) return MFSR_OK;
+    TRY(wait_ref_products(b, stream));
     for (int i = 0; i < kRing; i++)
         if (b->fusedOutstanding[i]) {
             MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evFused[i], 0));
@@ -1407,6 +1445,7 @@ extern "C" int mfsr_burst_fuse_rows(mfsr_burst* b, int nFrames, const uint16_t* 
 {
     MFSR_REQUIRE(b && raws && flows && masks && imgOut && totalWeights && nFrames >= 1 && nFrames <= MFSR_MAX_FUSE_GROUP);
     MFSR_REQUIRE(b->haveRef);
+    TRY(wait_ref_products(b, stream));
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
     const mfsr_float3 white = {c.white[0], c.white[1], c.white[2]};
@@ -1558,9 +1597,15 @@ extern "C" int mfsr_burst_set_reference_host(mfsr_burst* b, const uint16_t* host
     TRY(flush_pending(b, stream, false));    // a frame still waiting reads the previous reference's slots
     const int i = b->refCounter++ & 1;
     const int us = b->cfg.uploadRing + i;
-    // the slot's previous reference (two bursts ago) was last read by work already enqueued on the compute stream
-    MFSR_HIP_TRY(hipEventRecord(b->evFree[us], mfsr_s(stream)));
-    b->freeRecorded[us] = true;
+    // The slot's previous reference (two bursts ago) was released by that burst's mfsr_burst_finish_host -- so that this
+    // upload does not wait for the tail of the burst before this one, which is still being fused and downloaded when
+    // bursts come back to back.  A burst that ended another way: the slot was last read by work already enqueued on the
+    // compute stream.
+    if (!b->freeRecorded[us]) {
+        MFSR_HIP_TRY(hipEventRecord(b->evFree[us], mfsr_s(stream)));
+        b->freeRecorded[us] = true;
+    }
+    b->refSlot = us;
     TRY(upload_into(b, us, b->L.refRaw[i], hostRaw, stream));
     b->refHost = hostRaw;
     b->refDev = b->L.refRaw[i];
@@ -1602,6 +1647,17 @@ extern "C" int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw,
 // hand-written copy kernel with a 32-workgroup grid: it is the store path that clogs, not the wave slots.
 // (One more stream in the context -- a second upload stream was tried -- maps two streams onto one hardware queue and costs
 // 4 ms per burst: the context stays at its four streams.)
+// every reader of the burst's host reference has been enqueued on `stream`: its upload slot may be refilled after them
+static int release_ref_slot(mfsr_burst* b, mfsr_stream_t stream)
+{
+    if (b->refSlot >= 0) {
+        MFSR_HIP_TRY(hipEventRecord(b->evFree[b->refSlot], mfsr_s(stream)));
+        b->freeRecorded[b->refSlot] = true;
+        b->refSlot = -1;
+    }
+    return MFSR_OK;
+}
+
 extern "C" int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights,
                                       uint16_t* out16Dev, uint16_t* out16Host, mfsr_stream_t stream)
 {
@@ -1632,7 +1688,7 @@ extern "C" int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, 
                                       b->downStream));
         MFSR_HIP_TRY(hipEventRecord(b->evDown, b->downStream));
         b->downRecorded = true;
-        return MFSR_OK;
+        return release_ref_slot(b, stream);
     }
     mfsr_burst::Pending p = b->pend, p0;
     p0.n = 0;
@@ -1708,7 +1764,7 @@ extern "C" int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, 
     }
     MFSR_HIP_TRY(hipEventRecord(b->evDown, b->downStream));
     b->downRecorded = true;
-    return MFSR_OK;
+    return release_ref_slot(b, stream);
 }
 
 extern "C" int mfsr_burst_host_sync(mfsr_burst* b)

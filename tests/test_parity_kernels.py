@@ -296,6 +296,85 @@ def test_accumulate_groups_of_three_and_four(orc, hip, n, field, s, pat, fresh):
     assert np.abs(hw_).max() > 0.5
 
 
+def _accumulate_group_hip(hip, frames, kp, fw, fh, W, H, s, white, black, acc_i, acc_w, fresh):
+    import torch
+    dev = hip.dev
+    n = len(frames)
+    d_raw = [torch.from_numpy(f[0].view(np.int16)).to(dev) for f in frames]
+    d_mask = [torch.from_numpy(f[1]).to(dev) for f in frames]
+    d_sh = [torch.from_numpy(f[2]).to(dev) for f in frames]
+    d_kp = torch.from_numpy(kp).to(dev)
+    d_i, d_w = torch.from_numpy(acc_i).to(dev), torch.from_numpy(acc_w).to(dev)
+    P = ctypes.c_void_p * n
+    T = hip.capi.Tex2D * n
+    shs = T(*[hip.capi.Tex2D(t.data_ptr(), fw * 8, fw, fh) for t in d_sh])
+    hip.L.accumulateSuperResFullN(n, P(*[t.data_ptr() for t in d_raw]), d_i.data_ptr(), d_w.data_ptr(),
+                                  P(*[t.data_ptr() for t in d_mask]), hip.capi.Tex2D(d_kp.data_ptr(), fw * 16, fw, fh), shs,
+                                  hip.capi.f3(white.v), hip.capi.f3(black.v), W, H, s, pitch_of(acc_i), pitch_of(frames[0][1]), fresh, None)
+    torch.cuda.synchronize()
+    return d_i.cpu().numpy(), d_w.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,field,s,pat", [(4, "quarter", 2, "RGGB"), (4, "quarter", 2, "GBRG"), (3, "quarter", 2, "BGGR"), (2, "quarter", 2, "GRBG"),
+                                           (4, "half", 2, "MONO"), (4, "quarter", 4, "RGGB"), (2, "quarter", 4, "GBRG")])
+def test_accumulate_saturated_certainty_path(orc, hip, n, field, s, pat):
+    """The tile kernels take a cheaper pixel body for the frames whose certainty is exactly (1, 1, 1) on every texel a wave
+    reads (strip_pixel_sat: the robustness mask saturates over well-aligned content).  Masks here are saturated over
+    whole frames, over parts of a frame, everywhere but isolated texels, and not at all -- so neighbouring waves take
+    different bodies -- against the oracle; and the two bodies are BIT-identical where they compute the same pixel: a
+    frame of ones (saturated body) against ones with one texel column in 64 lowered (general body in every wave), compared
+    on the pixels whose taps do not read a lowered texel."""
+    W, H = 840, 88
+    cfa = [1, 1, 1, 1] if pat == "MONO" else PATTERNS[pat]
+    orc.set_cfa(cfa)
+    hip.set_cfa(cfa)
+    white, black = F3([3839, 3700, 3900]), F3([256, 260, 250])
+    fh, fw = {"quarter": (H // 2, W // 2), "half": (H, W)}[field]
+    kp = _kernel_field(270, fh, fw, 4)
+    yy, xx = np.mgrid[0:fh, 0:fw].astype(np.float32)
+    mh, mw = (H + 1) // 2, (W + 1) // 2
+    r = rng(271)
+
+    def frame(k, mask):
+        raw, _, _, _ = _accum_inputs(272 + k, W, H, W * s, H * s)
+        sh = np.stack([1.3 - 0.9 * k + 0.01 * xx, -2.2 + 1.1 * k + 0.02 * yy], -1).astype(np.float32)
+        return raw, np.ascontiguousarray(mask.astype(np.float32)), np.ascontiguousarray(sh)
+
+    ones = np.ones((mh, mw, 4), np.float32)
+    part = ones.copy()
+    part[:, : mw // 3] = r.random((mh, mw // 3, 4), dtype=np.float32)          # left third unsaturated
+    part[mh // 2:, mw // 2: mw // 2 + 40, 1] = 0.999999                         # one channel just below 1
+    dots = ones.copy()
+    dots[r.integers(0, mh, 12), r.integers(0, mw, 12), r.integers(0, 3, 12)] = 0.25
+    dots[3, 5] = np.nan                                                         # sanitised to 0: not saturated
+    rand = r.random((mh, mw, 4), dtype=np.float32)
+    masks = [ones, part, dots, rand][:n] if n > 2 else [part, ones]
+    frames = [frame(k, m) for k, m in enumerate(masks)]
+    _, oi, ow, _ = _accum_inputs(299, W, H, W * s, H * s)
+    hi0, hw0 = oi.copy(), ow.copy()
+    for raw, m, sh in frames:
+        orc.call("accumulateSuperResFull", raw, oi, ow, m, Tex(kp), Tex(sh), white, black, W, H, s, pitch_of(oi), pitch_of(m))
+    hi, hw_ = _accumulate_group_hip(hip, frames, kp, fw, fh, W, H, s, white, black, hi0, hw0, 0)
+    np.testing.assert_allclose(hw_, ow, rtol=3e-5, atol=3e-5)
+    np.testing.assert_allclose(hi, oi, rtol=3e-5, atol=3e-5)
+
+    # the two bodies on the same pixels
+    lowered = ones.copy()
+    cols = np.arange(20, mw, 64)
+    lowered[:, cols] = 0.5
+    fa = [frame(k, ones) for k in range(n)]
+    fb = [frame(k, lowered) for k in range(n)]
+    z = np.zeros_like(hi0)
+    ai, aw = _accumulate_group_hip(hip, fa, kp, fw, fh, W, H, s, white, black, z.copy(), z.copy(), 1)
+    bi, bw = _accumulate_group_hip(hip, fb, kp, fw, fh, W, H, s, white, black, z.copy(), z.copy(), 1)
+    # HR column X reads mask cells (X + t) // (2 s), t = -2..2: keep the columns at least two cells from a lowered one
+    cell = np.arange(W * s) // (2 * s)
+    far = np.min(np.abs(cell[:, None] - cols[None, :]), axis=1) >= 2
+    assert far.mean() > 0.8
+    assert np.array_equal(ai[:, far], bi[:, far]) and np.array_equal(aw[:, far], bw[:, far])
+    assert not np.array_equal(aw[:, ~far], bw[:, ~far])
+
+
 @pytest.mark.parametrize("s", [2, 4])
 def test_accumulate_anisotropic_kernels(orc, hip, s):
     """Kernel parameters as ComputeKernelParam makes them at strong edges: inverse covariances with
