@@ -1579,7 +1579,12 @@ void launch_tile(dim3 grid, dim3 block, hipStream_t st, const TileFrames<NF>& fr
 {
     const int tilesX = (int)grid.x, tilesY = (int)grid.y;
     const int tilesPerXcd = g_strip_xcd_remap ? mfsr_cdiv(tilesX * tilesY, 8) : 0;
-    hipLaunchKernelGGL((k_accumulate2xTile<CFA, NF, FR>), dim3(tilesPerXcd ? 8 * tilesPerXcd : tilesX * tilesY), block, 0, st, fr,
+    // occupancy probe (A/B only): unused dynamic LDS so that fewer workgroups fit a CU
+    static const int ldsPad = [] {
+        const char* e = getenv("MFSR_TILE_LDS_PAD");
+        return e ? atoi(e) : 0;
+    }();
+    hipLaunchKernelGGL((k_accumulate2xTile<CFA, NF, FR>), dim3(tilesPerXcd ? 8 * tilesPerXcd : tilesX * tilesY), block, ldsPad, st, fr,
                        imgOut, tw, kp, glv, lv, dimX, dimY, strideOut, strideMask, cfaPacked, tilesX, tilesY, tilesPerXcd, fresh, tileY0);
 }
 
