@@ -706,11 +706,19 @@ __global__ void __launch_bounds__(256)
 #ifndef TILE_GROUP_BOTH_PLANES
 #define TILE_GROUP_BOTH_PLANES 1
 #endif
-#define TILE_WAVES_NF(NF) ((NF) == 1 ? TILE_WAVES : ((NF) > 2 && TILE_GROUP_BOTH_PLANES) ? 3 : TILE_WAVES2)
+#define TILE_WAVES_NF(NF) ((NF) == 1 ? TILE_WAVES : ((NF) > 2 && TILE_GROUP_BOTH_PLANES) ? (TILE_LDS_ALIAS_ON ? 4 : 3) : TILE_WAVES2)
 // several frames per launch: pixel-major order with the tap weights shared by the frames (0: frame-major, weights per
 // frame; two frames at most)
 #ifndef TILE_PIXEL_MAJOR
 #define TILE_PIXEL_MAJOR 1
+#endif
+#define TILE_LDS_ALIAS_ON (TILE_LDS_ALIAS && TILE_PIXEL_MAJOR && TILE_GROUP_BOTH_PLANES)
+// Four workgroups per CU for the group kernels (three and four frames, fields at HR/4): the weight-sum plane-set is staged
+// over the kernel-parameter and flow texels once every wave is past its last read of them (39 KiB of LDS instead of 48), and
+// the rounded flow of a strip is kept in 8:8 bits per pixel (8 registers instead of 16; strips with more than 127 HR pixels
+// of flow take the straight arithmetic), which fits the 128-register budget of four waves per SIMD.  0: three workgroups (A/B).
+#ifndef TILE_LDS_ALIAS
+#define TILE_LDS_ALIAS 1
 #endif
 // pixel-major loop: frames whose certainty is saturated over the wave's footprint take strip_pixel_sat (0: A/B)
 #ifndef TILE_SAT_PATH
@@ -743,8 +751,16 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
     const int bIdY = bIdYrel + tileY0;  // tileY0: first tile row of this launch's HR row window
     static_assert(FR == 4 || FR == 2, "field resolution");
     constexpr int FC = 256 / FR + 2, FROWS = 4 / FR + 2;  // field texels a tile touches: 66 x 3 (FR = 4), 130 x 4 (FR = 2)
-    __shared__ float4 sK[FROWS][FC];  // .w = 1 if the texel is PSD and finite, else 0
-    __shared__ float2 sF[NF][FROWS][FC];
+    constexpr int PL = (NF <= 2 || TILE_GROUP_BOTH_PLANES) ? 2 : 1;
+    // ALIAS: the field texels live in the (not yet staged) weight-sum plane-set; see TILE_LDS_ALIAS
+    constexpr bool ALIAS = TILE_LDS_ALIAS_ON && FR == 4 && NF > 2 && PL == 2;
+    __shared__ __attribute__((aligned(16))) float4 sAcc[PL][4][192];
+    __shared__ float4 sKown[ALIAS ? 1 : FROWS][ALIAS ? 1 : FC];
+    __shared__ float2 sFown[ALIAS ? 1 : NF][ALIAS ? 1 : FROWS][ALIAS ? 1 : FC];
+    static_assert(!ALIAS || sizeof(float4) * FROWS * FC + sizeof(float2) * NF * FROWS * FC <= sizeof(float4) * 4 * 192, "field texels fit a plane-set");
+    float4(*sK)[FC] = ALIAS ? (float4(*)[FC]) & sAcc[PL - 1][0][0] : (float4(*)[FC]) & sKown[0][0];  // .w = 1 if the texel is PSD and finite, else 0
+    float2(*sF)[FROWS][FC] = ALIAS ? (float2(*)[FROWS][FC])((char*)&sAcc[PL - 1][0][0] + sizeof(float4) * FROWS * FC)
+                                   : (float2(*)[FROWS][FC]) & sFown[0][0][0];
     __shared__ float4 sM[NF][3][TILE_COLS];
     __shared__ uint32_t sUnsat[3][TILE_COLS];  // bit n: frame n's certainty texel is not (1, 1, 1)  (TILE_SAT_PATH)
     __shared__ __attribute__((aligned(16))) float sColA[256];  // x fraction per HR column of the tile, -1 = not on the predicted texel
@@ -752,8 +768,6 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
     // accumulator staging: per wave and plane-set the wave's 3 KiB row segment, in memory order
     // (TILE_GROUP_BOTH_PLANES = 0, three and four frames per launch: one plane-set at a time through the same 3 KiB so that
     // four workgroups per CU fit the 160 KiB -- the weight sums wait in registers, the second plane-set's load is exposed)
-    constexpr int PL = (NF <= 2 || TILE_GROUP_BOTH_PLANES) ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) float4 sAcc[4][PL][192];
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int tx = bIdX * 64 + lx;
     const int Y = bIdY * 4 + ly;
@@ -845,18 +859,18 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             if (fresh) {
-                sAcc[ly][pl][j * 64 + lx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                sAcc[pl][ly][j * 64 + lx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             } else {
                 const size_t off = (size_t)(j * 64 + lx) * 16;
                 if (segByte + off + 16 <= rowBytes)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + off),
-                                                     (__attribute__((address_space(3))) void*)&sAcc[ly][pl][j * 64], 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)&sAcc[pl][ly][j * 64], 16, 0, 0);
             }
         }
     };
     if (rowLive) {
         stage_plane(gP, 0);
-        if (PL == 2) stage_plane(gW, 1);
+        if (PL == 2 && !ALIAS) stage_plane(gW, 1);  // (ALIAS: after the last read of the field texels, below)
     }
     __syncthreads();
     if (!rowLive) return;
@@ -910,9 +924,11 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
         // both frames before the next pixel starts -- 13 live registers instead of the 4 x 13 a frame-major loop would
         // have to keep (that was 214 VGPRs; recomputing them per frame was the faster frame-major form).
         // Pass 1, per frame: whole-pixel flow of the four pixels (packed 16:16) and the fast-path admission.
-        uint32_t sxy[NF][4];
+        // (ALIAS: 8:8 bits per pixel, sxy[n][0] = the four sx, sxy[n][1] = the four sy; else 16:16 per pixel)
+        uint32_t sxy[NF][ALIAS ? 2 : 4];
 #pragma unroll
         for (int n = 0; n < NF; n++) {
+            if constexpr (ALIAS) sxy[n][0] = sxy[n][1] = 0u;
             float2 Ft[2][SC];
 #pragma unroll
             for (int r = 0; r < 2; r++)
@@ -926,12 +942,24 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
                 const float uy = lerp4(Ft[0][ci].y, Ft[0][ci + 1].y, Ft[1][ci].y, Ft[1][ci + 1].y, av[k], b);
                 const int sx = round2i(ux * 2.0f), sy = round2i(uy * 2.0f);
                 const int qx = X0 + k + sx - 2, qy = Y + sy - 2;
-                // as below, with the rounded flow inside 16 signed bits (wilder strips take the straight arithmetic)
-                safe = safe && (uint32_t)(sx + (1 << 15)) < (2u << 15) && (uint32_t)(sy + (1 << 15)) < (2u << 15) &&
+                // as below, with the rounded flow inside 16 (8) signed bits (wilder strips take the straight arithmetic)
+                constexpr int SB = ALIAS ? 7 : 15;
+                safe = safe && (uint32_t)(sx + (1 << SB)) < (2u << SB) && (uint32_t)(sy + (1 << SB)) < (2u << SB) &&
                        (uint32_t)qx <= xmax && (uint32_t)qy <= ymax;
-                sxy[n][k] = ((uint32_t)sx & 0xffffu) | ((uint32_t)sy << 16);
+                if constexpr (ALIAS) {
+                    sxy[n][0] |= ((uint32_t)sx & 0xffu) << (8 * k);
+                    sxy[n][1] |= ((uint32_t)sy & 0xffu) << (8 * k);
+                } else {
+                    sxy[n][k] = ((uint32_t)sx & 0xffffu) | ((uint32_t)sy << 16);
+                }
             }
             if (safe) safeBits |= 1u << n;
+        }
+        if constexpr (ALIAS) {
+            // every wave of the workgroup is past its reads of sK / sF (the rows outside the frame left before the first
+            // barrier as whole workgroups): the weight-sum plane-set may land on them
+            __syncthreads();
+            stage_plane(gW, 1);
         }
         // Pass 2, per pixel: weights once, then frame after frame.  What the eight pixel-frame bodies share is taken
         // here once (each body is its own divergent region, the compiler does not hoist across them): the LDS address of
@@ -982,7 +1010,8 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
                     auto mval = [&](int jt, int cell, int e4) {
                         return *(const float*)((const char*)(mrow[jt] + n * (3 * TILE_COLS * 4) + cell * 4) + e4);
                     };
-                    const int sx = (int)(int16_t)(sxy[n][k] & 0xffffu), sy = (int)sxy[n][k] >> 16;
+                    const int sx = ALIAS ? (int)(int8_t)(sxy[n][0] >> (8 * k)) : (int)(int16_t)(sxy[n][ALIAS ? 0 : k] & 0xffffu);
+                    const int sy = ALIAS ? (int)(int8_t)(sxy[n][1] >> (8 * k)) : (int)sxy[n][ALIAS ? 0 : k] >> 16;
                     if (TILE_SAT_PATH && ((satW >> n) & 1u))
                         strip_pixel_sat<k, CFA>(X0 + k, Y, sx, sy, w, P, rawf, lv, aP, accW);
                     else
@@ -990,7 +1019,7 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
                 }
             }
             if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged plane-set has landed (long ago)
-            float* myP = (float*)&sAcc[ly][0][0] + lx * 12 + 3 * k;
+            float* myP = (float*)&sAcc[0][ly][0] + lx * 12 + 3 * k;
             myP[0] += aP[3 * k];
             myP[1] += aP[3 * k + 1];
             myP[2] += aP[3 * k + 2];
@@ -1063,7 +1092,7 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
     }
     // staged plane pl += this lane's 4 pixels x 3 channels
     auto add_plane = [&](int pl, const float* acc) {
-        float4* my = (float4*)((float*)&sAcc[ly][pl][0] + lx * 12);
+        float4* my = (float4*)((float*)&sAcc[pl][ly][0] + lx * 12);
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             float4 a = my[j];
@@ -1076,8 +1105,8 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
     // and keeps that set's result only -- these strips are a few per frame.
     auto slow_frames = [&](auto doP, auto doW, int plP, int plW) {
         constexpr bool DO_P = decltype(doP)::value, DO_W = decltype(doW)::value;
-        float* myP = (float*)&sAcc[ly][plP][0] + lx * 12;
-        float* myW = (float*)&sAcc[ly][plW][0] + lx * 12;
+        float* myP = (float*)&sAcc[plP][ly][0] + lx * 12;
+        float* myW = (float*)&sAcc[plW][ly][0] + lx * 12;
 #pragma unroll 1
         for (int n = 0; n < NF; n++) {
             if (!((safeBits >> n) & 1u) && stripLive) {
@@ -1112,7 +1141,7 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
             // stream: their (unchanged) chunks are not written back.  A fresh launch defines them (zero) instead.
             const size_t gb = segByte + off;
             const bool sideMargin = gb < (size_t)STRIP_MARGIN * 12 || gb + 16 > rowBytes - (size_t)STRIP_MARGIN * 12;
-            if (gb + 16 <= rowBytes && (fresh || !sideMargin)) *(float4*)(g + off) = sAcc[ly][pl][j * 64 + lx];
+            if (gb + 16 <= rowBytes && (fresh || !sideMargin)) *(float4*)(g + off) = sAcc[pl][ly][j * 64 + lx];
         }
     };
     using Yes = std::true_type;
