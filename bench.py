@@ -319,11 +319,12 @@ def main():
     if args.no_async_fuse:
         cfg.asyncFuse = 0
     if world == 1 and not local_group:
-        # device slots for --h2d and the end-to-end leg (mfsr_burst_*_host); unused by the resident run.  16 slots (the
-        # maximum): a whole 16-frame burst uploads without waiting for a slot (11.2 ms per 4K burst incl. the download of the
-        # result, against 14.9 / 15.6 ms with 4 / 8 slots; 8K x 8 is PCIe-bound at 19.2 ms whatever the depth,
-        # profiles/r02_h2d_ring_sweep.txt)
-        cfg.uploadRing = int(os.environ.get("MFSR_UPLOAD_RING", "16"))
+        # device slots for --h2d and the end-to-end leg (mfsr_burst_*_host); unused by the resident run.  16 slots: a whole
+        # 16-frame burst uploads without waiting for a slot (11.2 ms per 4K burst incl. the download of the result, against
+        # 14.9 / 15.6 ms with 4 / 8 slots; 8K x 8 is PCIe-bound at 19.2 ms whatever the depth,
+        # profiles/r02_h2d_ring_sweep.txt); 32 (the maximum): the next burst's frames upload under this burst's tail when
+        # bursts come back to back (end_to_end.back_to_back)
+        cfg.uploadRing = int(os.environ.get("MFSR_UPLOAD_RING", "32"))
     exchange = "stripes" if args.exchange == "auto" else args.exchange
     dist_impl = "torch" if backend == "gloo" else args.dist_impl
     # --force-dist: the multi-GPU code path with a world of one rank (one-rank RCCL communicator): rehearsal of what the

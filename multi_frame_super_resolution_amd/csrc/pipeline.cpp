@@ -39,7 +39,7 @@ constexpr int kMaxTimedLaunches = 4096;
 // untouched until the warp+fuse that consumes it has run, which with cfg.asyncFuse happens on the
 // burst's own stream while the caller's stream already aligns the next frames.
 constexpr int kRing = 2 * MFSR_MAX_FUSE_GROUP;  // a group waiting to be fused + the group the fuse stream is reading
-constexpr int kMaxUploadRing = 16;
+constexpr int kMaxUploadRing = 32;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -335,6 +335,7 @@ struct mfsr_burst {
     hipEvent_t evFree[kMaxUploadRing + 2];  // last consumer of the slot enqueued (compute / fuse stream)
     bool freeRecorded[kMaxUploadRing + 2];
     int refSlot;                            // upload slot of the current host reference (-1: none / released)
+    bool hostBusy;                          // this host burst was enqueued before the previous one's download had finished
     int upCounter, refCounter;
     const uint16_t* refHost;                // host pointer of the current reference and its device copy
     const uint16_t* refDev;
@@ -500,6 +501,7 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
         b->evUp[i] = b->evFree[i] = nullptr;
         b->freeRecorded[i] = false;
         b->refSlot = -1;
+        b->hostBusy = false;
     }
     if (cfg->uploadRing > 0) {
         hipError_t e = hipStreamCreateWithFlags(&b->copyStream, hipStreamNonBlocking);
@@ -1115,7 +1117,10 @@ static bool can_defer_alignment(const mfsr_burst* b)
         const char* e = getenv("MFSR_HOST_DEFER");
         return e && e[0] == '1';
     }();
-    const bool hostImmediate = b->holdLastGroup && (b->framesSinceRef < b->group || !hostDefer);
+    // ... and a host burst that was enqueued while the previous one was still being fused and downloaded (bursts back to
+    // back: b->hostBusy) batches every group: the GPU has work queued, so frame-by-frame launches buy no latency and cost
+    // a tenth of the alignment's throughput
+    const bool hostImmediate = b->holdLastGroup && !b->hostBusy && (b->framesSinceRef < b->group || !hostDefer);
     return on && b->group > 1 && b->L.nSets >= b->group - 1 && lk_warped_path(b) && c.lkHalfWindow >= 1 && c.lkHalfWindow <= 7 &&
            !b->movPrepared && !b->givenShifts && !hostImmediate;
 }
@@ -1595,6 +1600,11 @@ extern "C" int mfsr_burst_set_reference_host(mfsr_burst* b, const uint16_t* host
     MFSR_REQUIRE(b && hostRaw);
     MFSR_REQUIRE(b->copyStream != nullptr);  // cfg.uploadRing > 0
     TRY(flush_pending(b, stream, false));    // a frame still waiting reads the previous reference's slots
+    static const bool adaptive = [] {
+        const char* e = getenv("MFSR_HOST_ADAPTIVE");
+        return !(e && e[0] == '0');
+    }();
+    b->hostBusy = adaptive && b->downRecorded && hipEventQuery(b->evDown) == hipErrorNotReady;
     const int i = b->refCounter++ & 1;
     const int us = b->cfg.uploadRing + i;
     // The slot's previous reference (two bursts ago) was released by that burst's mfsr_burst_finish_host -- so that this
