@@ -513,6 +513,42 @@ def test_host_frame_burst_equals_device_frame_burst(ring, pair, async_fuse):
         pipe.close()
 
 
+@pytest.mark.parametrize("ring,group", [(32, 4), (9, 4), (5, 2), (16, 3)])
+def test_host_bursts_back_to_back_equal_single_bursts(ring, group):
+    """Host bursts enqueued back to back with NO host synchronisation between them (the next burst's uploads run under
+    this burst's banded tail and download; a burst that finds the previous one still in flight batches its alignment per
+    group, mfsr_burst_set_reference_host): every image equals the device-resident burst.  Two different bursts alternate,
+    so a stale upload slot, reference slot or kernel-parameter image of the other burst would show; rings both deeper and
+    shallower than a burst."""
+    import torch
+    from multi_frame_super_resolution_amd import synth
+    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, default_config
+    dev = torch.device("cuda:0")
+    W, H, N = 512, 384, 11
+    bursts = [synth.make_burst(W, H, N, seed=31 + i, device="cpu")[0] for i in range(2)]
+    cfg = default_config(W, H, N, scale=2)
+    cfg.reference = 2
+    cfg.pairFrames = group
+    plain = BurstPipeline(cfg, dev)
+    want = []
+    for fr in bursts:
+        _, w = plain.process([f.to(dev) for f in fr])
+        want.append(w.cpu().clone())
+    plain.close()
+    assert not torch.equal(want[0], want[1])
+    cfg.uploadRing = ring
+    pipe = BurstPipeline(cfg, dev)
+    pinned = [[f.pin_memory() for f in fr] for fr in bursts]
+    outs = [torch.zeros(H * 2, W * 2, 3, dtype=torch.int16).pin_memory() for _ in range(6)]
+    for i in range(6):
+        pipe.process_host(pinned[i & 1], outs[i])     # no host_sync in between
+    pipe.host_sync()
+    torch.cuda.synchronize()
+    for i in range(6):
+        assert torch.equal(outs[i], want[i & 1]), (ring, group, i)
+    pipe.close()
+
+
 @pytest.mark.parametrize("ref_index", [0, 2])
 def test_joint_minimiser_burst_matches_oracle(ref_index):
     """Stage C in the pipeline (mfsr_burst_process_joint): neighbouring pairs measured besides the (reference, k) pairs,
