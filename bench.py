@@ -233,6 +233,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="N=1: run the step through mfsr_dist_* (one-rank communicator) -- rehearsal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the H2D->D2H end-to-end leg (median of 20 bursts)")
+    ap.add_argument("--no-isolated", action="store_true",
+                    help="skip the stand-alone warp+fuse leg (with --no-e2e --no-cpu-baseline a profile of the run then holds only "
+                         "the bursts of the warm-up and the timed region: profiles/*_kernel_stats_timed_region.csv)")
     ap.add_argument("--cpu-sample-frames", type=int, default=4)
     ap.add_argument("--unfused", action="store_true", help="one launch per reference kernel (A/B against the fused path)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -244,7 +247,7 @@ def main():
                     "one launch takes, 4 at x2 Bayer, else 2)")
     ap.add_argument("--async-fuse", action="store_true", help="(default since round 2: cfg.asyncFuse = 1) accepted for compatibility")
     ap.add_argument("--no-async-fuse", action="store_true",
-                    help="cfg.asyncFuse = 0: warp+fuse launches on the caller's stream instead of the burst's own (A/B: -5 %)")
+                    help="cfg.asyncFuse = 0: warp+fuse launches on the caller's stream instead of the burst's own (A/B: -5 %%)")
     ap.add_argument("--h2d", action="store_true",
                     help="N=1 only: frames start in pinned HOST memory and stream through a 4-deep device ring on a copy "
                          "stream (the PCIe-inclusive rate quoted in DESIGN.md; `value` of the contract is the HBM-resident run)")
@@ -530,7 +533,7 @@ def main():
     # following frames, which stretches them.  A short extra leg times the same launches WITHOUT that overlap (launches back to
     # back on one stream) so that the line also carries the kernel's stand-alone figure.
     isolated = None
-    if world == 1 and rank == 0 and pipe is not None and cfg.asyncFuse and not h2d:
+    if world == 1 and rank == 0 and pipe is not None and cfg.asyncFuse and not h2d and not args.no_isolated:
         cfg_iso = default_config(W, H, n_frames, s, mono)
         cfg_iso.fused, cfg_iso.pairFrames, cfg_iso.asyncFuse = cfg.fused, cfg.pairFrames, 0
         p_iso = BurstPipeline(cfg_iso, dev)
