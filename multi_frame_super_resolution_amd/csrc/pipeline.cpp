@@ -472,7 +472,13 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     if (cfg->asyncFuse) {
         int lo = 0, hi = 0;
         hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->fuseStream, hipStreamNonBlocking, hi);
+        // MFSR_FUSE_PRIO=low|normal (A/B): the fuse stream's priority against the caller's (default: high)
+        static const int prioMode = [] {
+            const char* v = getenv("MFSR_FUSE_PRIO");
+            return !v ? 0 : (v[0] == 'l' ? 1 : (v[0] == 'n' ? 2 : 0));
+        }();
+        const int prio = prioMode == 1 ? lo : (prioMode == 2 ? (lo + hi) / 2 : hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->fuseStream, hipStreamNonBlocking, prio);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evRefStart, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b->evRefDone, hipEventDisableTiming);
         for (int i = 0; i < kRing && e == hipSuccess; i++) {
