@@ -1610,7 +1610,13 @@ extern "C" int mfsr_burst_set_reference_host(mfsr_burst* b, const uint16_t* host
         const char* e = getenv("MFSR_HOST_ADAPTIVE");
         return !(e && e[0] == '0');
     }();
-    b->hostBusy = adaptive && b->downRecorded && hipEventQuery(b->evDown) == hipErrorNotReady;
+    b->hostBusy = false;
+    if (adaptive && b->downRecorded) {
+        // (an event query is not allowed while the caller's stream is being captured into a graph)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(mfsr_s(stream), &cap) == hipSuccess && cap == hipStreamCaptureStatusNone)
+            b->hostBusy = hipEventQuery(b->evDown) == hipErrorNotReady;
+    }
     const int i = b->refCounter++ & 1;
     const int us = b->cfg.uploadRing + i;
     // The slot's previous reference (two bursts ago) was released by that burst's mfsr_burst_finish_host -- so that this
