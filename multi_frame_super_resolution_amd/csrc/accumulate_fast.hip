@@ -1288,8 +1288,9 @@ __device__ __forceinline__ void strip_pixel4(int X, int Y, int sx, int sy, float
 #ifndef TILE4_WAVES2
 #define TILE4_WAVES2 3
 #endif
+// (three and four frames per launch: four workgroups per CU by the layout of TILE_LDS_ALIAS, see k_accumulate2xTile)
 template <int CFA, int NF>
-__global__ void __launch_bounds__(256, (NF) == 1 ? 4 : TILE4_WAVES2)
+__global__ void __launch_bounds__(256, (NF) == 1 ? 4 : ((NF) > 2 && TILE_LDS_ALIAS_ON) ? 4 : TILE4_WAVES2)
     k_accumulate4xTile(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
                        Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked,
                        int tilesX, int fresh, int tileY0)
@@ -1299,12 +1300,18 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : TILE4_WAVES2)
     const int hrW = 4 * dimX, hrH = 4 * dimY;
     const int Y0 = 2 * bIdY;
     if (Y0 < STRIP_MARGIN || Y0 >= hrH - STRIP_MARGIN) return;  // whole workgroup (margin rows)
-    __shared__ float4 sK[3][TILE_COLS];  // .w = 1 if the texel is PSD and finite, else 0
-    __shared__ float2 sF[NF][3][TILE_COLS];
+    constexpr bool ALIAS = TILE_LDS_ALIAS_ON && NF > 2;
+    __shared__ __attribute__((aligned(16))) float4 sAcc[2][2][384];  // [plane-set][row][6 KiB row segment]
+    __shared__ float4 sKown[ALIAS ? 1 : 3][ALIAS ? 1 : TILE_COLS];
+    __shared__ float2 sFown[ALIAS ? 1 : NF][ALIAS ? 1 : 3][ALIAS ? 1 : TILE_COLS];
+    static_assert(!ALIAS || sizeof(float4) * 3 * TILE_COLS + sizeof(float2) * NF * 3 * TILE_COLS <= sizeof(float4) * 2 * 384, "field texels fit a plane-set");
+    // ALIAS: the field texels live in the weight-sum plane-set's staging area until every wave has read them (TILE_LDS_ALIAS)
+    float4(*sK)[TILE_COLS] = ALIAS ? (float4(*)[TILE_COLS]) & sAcc[1][0][0] : (float4(*)[TILE_COLS]) & sKown[0][0];  // .w = 1 if PSD and finite
+    float2(*sF)[3][TILE_COLS] = ALIAS ? (float2(*)[3][TILE_COLS])((char*)&sAcc[1][0][0] + sizeof(float4) * 3 * TILE_COLS)
+                                      : (float2(*)[3][TILE_COLS]) & sFown[0][0][0];
     __shared__ float4 sM[NF][3][TILE_COLS];
     __shared__ __attribute__((aligned(16))) float sColA[512];
     __shared__ float sRowB[2];
-    __shared__ __attribute__((aligned(16))) float4 sAcc[2][2][384];  // [row][plane-set][6 KiB row segment]
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int r = ly >> 1, h = ly & 1;
     const int X0 = bIdX * 512 + 8 * lx + 4 * h;
@@ -1358,24 +1365,21 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : TILE4_WAVES2)
     const size_t segByte = (size_t)bIdX * 6144 + (size_t)h * 3072;
     char* gP = (char*)imgOut + (size_t)Y * strideOut + segByte;
     char* gW = (char*)totalWeights + (size_t)Y * strideOut + segByte;
-    if (fresh) {
+    auto stage_plane = [&](char* g, int pl) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            sAcc[r][0][h * 192 + j * 64 + lx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            sAcc[r][1][h * 192 + j * 64 + lx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const size_t off = (size_t)(j * 64 + lx) * 16;
-            if (segByte + off + 16 <= rowBytes) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gP + off),
-                                                 (__attribute__((address_space(3))) void*)&sAcc[r][0][h * 192 + j * 64], 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW + off),
-                                                 (__attribute__((address_space(3))) void*)&sAcc[r][1][h * 192 + j * 64], 16, 0, 0);
+            if (fresh) {
+                sAcc[pl][r][h * 192 + j * 64 + lx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            } else {
+                const size_t off = (size_t)(j * 64 + lx) * 16;
+                if (segByte + off + 16 <= rowBytes)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + off),
+                                                     (__attribute__((address_space(3))) void*)&sAcc[pl][r][h * 192 + j * 64], 16, 0, 0);
             }
         }
-    }
+    };
+    stage_plane(gP, 0);
+    if (!ALIAS) stage_plane(gW, 1);  // (ALIAS: after the last read of the field texels, below)
     __syncthreads();
     const bool stripLive = X0 >= STRIP_MARGIN && X0 < hrW - STRIP_MARGIN;
 
@@ -1418,9 +1422,10 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : TILE4_WAVES2)
     if constexpr (NF > 1) {
         // pixel-major, as k_accumulate2xTile: per frame the whole-pixel flow of the strip's pixels and the admission, then
         // per pixel the tap weights once and frame after frame
-        uint32_t sxy[NF][4];
+        uint32_t sxy[NF][ALIAS ? 2 : 4];  // (ALIAS: 8:8 bits per pixel, [0] = the four sx, [1] = the four sy)
 #pragma unroll
         for (int n = 0; n < NF; n++) {
+            if constexpr (ALIAS) sxy[n][0] = sxy[n][1] = 0u;
             float2 Ft[2][2];
 #pragma unroll
             for (int r2 = 0; r2 < 2; r2++)
@@ -1433,11 +1438,21 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : TILE4_WAVES2)
                 const float uy = lerp4(Ft[0][0].y, Ft[0][1].y, Ft[1][0].y, Ft[1][1].y, av[k], b);
                 const int sx = round2i(ux * 4.0f), sy = round2i(uy * 4.0f);
                 const int qx = X0 + k + sx - 2, qy = Y + sy - 2;
-                safe = safe && (uint32_t)(sx + (1 << 15)) < (2u << 15) && (uint32_t)(sy + (1 << 15)) < (2u << 15) &&
+                constexpr int SB = ALIAS ? 7 : 15;
+                safe = safe && (uint32_t)(sx + (1 << SB)) < (2u << SB) && (uint32_t)(sy + (1 << SB)) < (2u << SB) &&
                        (uint32_t)qx <= xmax && (uint32_t)qy <= ymax;
-                sxy[n][k] = ((uint32_t)sx & 0xffffu) | ((uint32_t)sy << 16);
+                if constexpr (ALIAS) {
+                    sxy[n][0] |= ((uint32_t)sx & 0xffu) << (8 * k);
+                    sxy[n][1] |= ((uint32_t)sy & 0xffu) << (8 * k);
+                } else {
+                    sxy[n][k] = ((uint32_t)sx & 0xffffu) | ((uint32_t)sy << 16);
+                }
             }
             if (safe) safeBits |= 1u << n;
+        }
+        if constexpr (ALIAS) {
+            __syncthreads();  // every wave is past its reads of sK / sF
+            stage_plane(gW, 1);
         }
         const float* mrow[5];
 #pragma unroll
@@ -1465,7 +1480,8 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : TILE4_WAVES2)
                         }
                     };
                     auto mval = [&](int jt, int cell, int e) { return mrow[jt][n * (3 * TILE_COLS * 4) + cell * 4 + e]; };
-                    const int sx = (int)(int16_t)(sxy[n][k] & 0xffffu), sy = (int)sxy[n][k] >> 16;
+                    const int sx = ALIAS ? (int)(int8_t)(sxy[n][0] >> (8 * k)) : (int)(int16_t)(sxy[n][ALIAS ? 0 : k] & 0xffffu);
+                    const int sy = ALIAS ? (int)(int8_t)(sxy[n][1] >> (8 * k)) : (int)sxy[n][ALIAS ? 0 : k] >> 16;
                     strip_pixel4_w<K8, CFA, true>(X0 + k, Y, sx, sy, w, rawf, mval, lv, accP, accW);
                 }
             }
@@ -1534,8 +1550,8 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : TILE4_WAVES2)
     // every wave's part of the staged rows must have landed before any lane updates them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    float* myP = (float*)&sAcc[r][0][0] + (2 * lx + h) * 12;
-    float* myW = (float*)&sAcc[r][1][0] + (2 * lx + h) * 12;
+    float* myP = (float*)&sAcc[0][r][0] + (2 * lx + h) * 12;
+    float* myW = (float*)&sAcc[1][r][0] + (2 * lx + h) * 12;
     if (safeBits) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -1575,8 +1591,8 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : TILE4_WAVES2)
         const size_t g = segByte + off;  // side-margin chunks: see k_accumulate2xTile
         const bool sideMargin = g < (size_t)STRIP_MARGIN * 12 || g + 16 > rowBytes - (size_t)STRIP_MARGIN * 12;
         if (g + 16 <= rowBytes && (fresh || !sideMargin)) {
-            *(float4*)(gP + off) = sAcc[r][0][h * 192 + j * 64 + lx];
-            *(float4*)(gW + off) = sAcc[r][1][h * 192 + j * 64 + lx];
+            *(float4*)(gP + off) = sAcc[0][r][h * 192 + j * 64 + lx];
+            *(float4*)(gW + off) = sAcc[1][r][h * 192 + j * 64 + lx];
         }
     }
 }
