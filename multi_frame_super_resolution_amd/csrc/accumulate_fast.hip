@@ -345,18 +345,15 @@ __device__ __forceinline__ void strip_pixel_sat(int X, int Y, int sx, int sy, co
     const uint32_t mP = 0u - (uint32_t)(x0 & 1), mQ = 0u - (uint32_t)(y0 & 1);
     float s[3][3];
     rawf(x0, y0, s);
+    auto W_ = [&](int jt, int it) { const int n = jt * 5 + it; return w[n <= 12 ? n : 24 - n]; };
+    // W(jt, i) + W(jt, i + 1): tap rows 3 and 4 are rows 1 and 0 read backwards (w[n] == w[24 - n])
+    auto P_ = [&](int jt, int i) { return jt <= 2 ? P[jt][i] : P[4 - jt][3 - i]; };
     float C[5][3];
 #pragma unroll
     for (int jt = 0; jt < 5; jt++) {
-        // tap row jt = row r read forwards (jt <= 2) or backwards (jt >= 3: w[n] == w[24 - n])
-        const int r = jt <= 2 ? jt : 4 - jt;
-        const bool rev = jt >= 3;
-        const float W0 = w[5 * r + (rev ? 4 : 0) <= 12 ? 5 * r + (rev ? 4 : 0) : 24 - (5 * r + (rev ? 4 : 0))];
-        const float W4 = w[5 * r + (rev ? 0 : 4) <= 12 ? 5 * r + (rev ? 0 : 4) : 24 - (5 * r + (rev ? 0 : 4))];
-        const float P01 = P[r][rev ? 3 : 0], P12 = P[r][rev ? 2 : 1], P23 = P[r][rev ? 1 : 2], P34 = P[r][rev ? 0 : 3];
-        C[jt][0] = selm(mbx, W0, P01);   // tap 0, tap 1 if bx == 0
-        C[jt][1] = selm(mbx, P12, P23);  // tap 1 if bx == 1, tap 2, tap 3 if bx == 0
-        C[jt][2] = selm(mbx, P34, W4);   // tap 3 if bx == 1, tap 4
+        C[jt][0] = selm(mbx, W_(jt, 0), P_(jt, 0));   // tap 0, tap 1 if bx == 0
+        C[jt][1] = selm(mbx, P_(jt, 1), P_(jt, 2));   // tap 1 if bx == 1, tap 2, tap 3 if bx == 0
+        C[jt][2] = selm(mbx, P_(jt, 3), W_(jt, 4));   // tap 3 if bx == 1, tap 4
     }
     strip_pixel_sites<K, CFA>(C, s, mby, nby, mP, mQ, lv, accP, accW);
 }
