@@ -712,8 +712,8 @@ __global__ void __launch_bounds__(256)
 #define TILE_LDS_ALIAS_ON (TILE_LDS_ALIAS && TILE_PIXEL_MAJOR && TILE_GROUP_BOTH_PLANES)
 // Four workgroups per CU for the group kernels (three and four frames, fields at HR/4): the weight-sum plane-set is staged
 // over the kernel-parameter and flow texels once every wave is past its last read of them (39 KiB of LDS instead of 48), and
-// the rounded flow of a strip is kept in 8:8 bits per pixel (8 registers instead of 16; strips with more than 127 HR pixels
-// of flow take the straight arithmetic), which fits the 128-register budget of four waves per SIMD.  0: three workgroups (A/B).
+// the rounded flow of a strip is kept in 8:8 bits per pixel relative to the tile's own rounded flow (8 registers instead of 16;
+// strips more than 127 HR pixels away from it take the straight arithmetic), which fits the 128-register budget of four waves per SIMD.  0: three workgroups (A/B).
 #ifndef TILE_LDS_ALIAS
 #define TILE_LDS_ALIAS 1
 #endif
@@ -923,9 +923,18 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
         // Pass 1, per frame: whole-pixel flow of the four pixels (packed 16:16) and the fast-path admission.
         // (ALIAS: 8:8 bits per pixel, sxy[n][0] = the four sx, sxy[n][1] = the four sy; else 16:16 per pixel)
         uint32_t sxy[NF][ALIAS ? 2 : 4];
+        // (ALIAS: the 8 bits hold the flow RELATIVE to the rounded flow of the tile's centre texel, a per-frame scalar -- so
+        // a large global shift of a frame costs nothing; a strip more than 127 HR pixels away from it takes the straight path)
+        int bsx[NF], bsy[NF];
 #pragma unroll
         for (int n = 0; n < NF; n++) {
-            if constexpr (ALIAS) sxy[n][0] = sxy[n][1] = 0u;
+            bsx[n] = bsy[n] = 0;
+            if constexpr (ALIAS) {
+                sxy[n][0] = sxy[n][1] = 0u;
+                const float2 cf = sF[n][1][FC / 2];
+                bsx[n] = __builtin_amdgcn_readfirstlane(min(max(round2i(cf.x * 2.0f), -32000), 32000));
+                bsy[n] = __builtin_amdgcn_readfirstlane(min(max(round2i(cf.y * 2.0f), -32000), 32000));
+            }
             float2 Ft[2][SC];
 #pragma unroll
             for (int r = 0; r < 2; r++)
@@ -939,13 +948,14 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
                 const float uy = lerp4(Ft[0][ci].y, Ft[0][ci + 1].y, Ft[1][ci].y, Ft[1][ci + 1].y, av[k], b);
                 const int sx = round2i(ux * 2.0f), sy = round2i(uy * 2.0f);
                 const int qx = X0 + k + sx - 2, qy = Y + sy - 2;
-                // as below, with the rounded flow inside 16 (8) signed bits (wilder strips take the straight arithmetic)
-                constexpr int SB = ALIAS ? 7 : 15;
-                safe = safe && (uint32_t)(sx + (1 << SB)) < (2u << SB) && (uint32_t)(sy + (1 << SB)) < (2u << SB) &&
+                // as below, with the rounded flow inside 16 signed bits (wilder strips take the straight arithmetic)
+                safe = safe && (uint32_t)(sx + (1 << 15)) < (2u << 15) && (uint32_t)(sy + (1 << 15)) < (2u << 15) &&
                        (uint32_t)qx <= xmax && (uint32_t)qy <= ymax;
                 if constexpr (ALIAS) {
-                    sxy[n][0] |= ((uint32_t)sx & 0xffu) << (8 * k);
-                    sxy[n][1] |= ((uint32_t)sy & 0xffu) << (8 * k);
+                    const int dx = sx - bsx[n], dy = sy - bsy[n];  // (no overflow: both inside 16 bits when it matters)
+                    safe = safe && (uint32_t)(dx + 128) < 256u && (uint32_t)(dy + 128) < 256u;
+                    sxy[n][0] |= ((uint32_t)dx & 0xffu) << (8 * k);
+                    sxy[n][1] |= ((uint32_t)dy & 0xffu) << (8 * k);
                 } else {
                     sxy[n][k] = ((uint32_t)sx & 0xffffu) | ((uint32_t)sy << 16);
                 }
@@ -1007,8 +1017,8 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
                     auto mval = [&](int jt, int cell, int e4) {
                         return *(const float*)((const char*)(mrow[jt] + n * (3 * TILE_COLS * 4) + cell * 4) + e4);
                     };
-                    const int sx = ALIAS ? (int)(int8_t)(sxy[n][0] >> (8 * k)) : (int)(int16_t)(sxy[n][ALIAS ? 0 : k] & 0xffffu);
-                    const int sy = ALIAS ? (int)(int8_t)(sxy[n][1] >> (8 * k)) : (int)sxy[n][ALIAS ? 0 : k] >> 16;
+                    const int sx = ALIAS ? bsx[n] + (int)(int8_t)(sxy[n][0] >> (8 * k)) : (int)(int16_t)(sxy[n][ALIAS ? 0 : k] & 0xffffu);
+                    const int sy = ALIAS ? bsy[n] + (int)(int8_t)(sxy[n][1] >> (8 * k)) : (int)sxy[n][ALIAS ? 0 : k] >> 16;
                     if (TILE_SAT_PATH && ((satW >> n) & 1u))
                         strip_pixel_sat<k, CFA>(X0 + k, Y, sx, sy, w, P, rawf, lv, aP, accW);
                     else
@@ -1419,10 +1429,17 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : ((NF) > 2 && TILE_LDS_ALI
     if constexpr (NF > 1) {
         // pixel-major, as k_accumulate2xTile: per frame the whole-pixel flow of the strip's pixels and the admission, then
         // per pixel the tap weights once and frame after frame
-        uint32_t sxy[NF][ALIAS ? 2 : 4];  // (ALIAS: 8:8 bits per pixel, [0] = the four sx, [1] = the four sy)
+        uint32_t sxy[NF][ALIAS ? 2 : 4];  // (ALIAS: 8:8 bits per pixel, [0] = the four sx, [1] = the four sy, relative to bsx / bsy)
+        int bsx[NF], bsy[NF];             // rounded flow of the tile's centre texel (per-frame scalars), see k_accumulate2xTile
 #pragma unroll
         for (int n = 0; n < NF; n++) {
-            if constexpr (ALIAS) sxy[n][0] = sxy[n][1] = 0u;
+            bsx[n] = bsy[n] = 0;
+            if constexpr (ALIAS) {
+                sxy[n][0] = sxy[n][1] = 0u;
+                const float2 cf = sF[n][1][TILE_COLS / 2];
+                bsx[n] = __builtin_amdgcn_readfirstlane(min(max(round2i(cf.x * 4.0f), -32000), 32000));
+                bsy[n] = __builtin_amdgcn_readfirstlane(min(max(round2i(cf.y * 4.0f), -32000), 32000));
+            }
             float2 Ft[2][2];
 #pragma unroll
             for (int r2 = 0; r2 < 2; r2++)
@@ -1435,12 +1452,13 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : ((NF) > 2 && TILE_LDS_ALI
                 const float uy = lerp4(Ft[0][0].y, Ft[0][1].y, Ft[1][0].y, Ft[1][1].y, av[k], b);
                 const int sx = round2i(ux * 4.0f), sy = round2i(uy * 4.0f);
                 const int qx = X0 + k + sx - 2, qy = Y + sy - 2;
-                constexpr int SB = ALIAS ? 7 : 15;
-                safe = safe && (uint32_t)(sx + (1 << SB)) < (2u << SB) && (uint32_t)(sy + (1 << SB)) < (2u << SB) &&
+                safe = safe && (uint32_t)(sx + (1 << 15)) < (2u << 15) && (uint32_t)(sy + (1 << 15)) < (2u << 15) &&
                        (uint32_t)qx <= xmax && (uint32_t)qy <= ymax;
                 if constexpr (ALIAS) {
-                    sxy[n][0] |= ((uint32_t)sx & 0xffu) << (8 * k);
-                    sxy[n][1] |= ((uint32_t)sy & 0xffu) << (8 * k);
+                    const int dx = sx - bsx[n], dy = sy - bsy[n];
+                    safe = safe && (uint32_t)(dx + 128) < 256u && (uint32_t)(dy + 128) < 256u;
+                    sxy[n][0] |= ((uint32_t)dx & 0xffu) << (8 * k);
+                    sxy[n][1] |= ((uint32_t)dy & 0xffu) << (8 * k);
                 } else {
                     sxy[n][k] = ((uint32_t)sx & 0xffffu) | ((uint32_t)sy << 16);
                 }
@@ -1477,8 +1495,8 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : ((NF) > 2 && TILE_LDS_ALI
                         }
                     };
                     auto mval = [&](int jt, int cell, int e) { return mrow[jt][n * (3 * TILE_COLS * 4) + cell * 4 + e]; };
-                    const int sx = ALIAS ? (int)(int8_t)(sxy[n][0] >> (8 * k)) : (int)(int16_t)(sxy[n][ALIAS ? 0 : k] & 0xffffu);
-                    const int sy = ALIAS ? (int)(int8_t)(sxy[n][1] >> (8 * k)) : (int)sxy[n][ALIAS ? 0 : k] >> 16;
+                    const int sx = ALIAS ? bsx[n] + (int)(int8_t)(sxy[n][0] >> (8 * k)) : (int)(int16_t)(sxy[n][ALIAS ? 0 : k] & 0xffffu);
+                    const int sy = ALIAS ? bsy[n] + (int)(int8_t)(sxy[n][1] >> (8 * k)) : (int)sxy[n][ALIAS ? 0 : k] >> 16;
                     strip_pixel4_w<K8, CFA, true>(X0 + k, Y, sx, sy, w, rawf, mval, lv, accP, accW);
                 }
             }

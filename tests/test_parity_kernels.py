@@ -375,6 +375,36 @@ def test_accumulate_saturated_certainty_path(orc, hip, n, field, s, pat):
     assert not np.array_equal(aw[:, ~far], bw[:, ~far])
 
 
+@pytest.mark.parametrize("s,base", [(2, (70.3, -40.2)), (4, (70.3, -40.2)), (2, (-150.6, 33.0)), (4, (12.2, 90.7))])
+def test_accumulate_large_global_shift(orc, hip, s, base):
+    """Frames displaced by tens to hundreds of pixels as a whole (a hand-held burst before any stabilisation): the group
+    kernels keep the rounded flow of a strip in 8 bits per pixel RELATIVE to the rounded flow of the tile's centre texel,
+    so such frames stay on the fast path wherever their taps are inside the frame -- against the oracle, with one frame
+    whose flow also varies by more than 127 HR pixels inside a tile (those strips take the straight arithmetic)."""
+    W, H, n = 840, 328, 4
+    orc.set_cfa(PATTERNS["RGGB"])
+    hip.set_cfa(PATTERNS["RGGB"])
+    white, black = F3([3839, 3700, 3900]), F3([256, 260, 250])
+    fh, fw = H // 2, W // 2
+    kp = _kernel_field(370, fh, fw, 4)
+    yy, xx = np.mgrid[0:fh, 0:fw].astype(np.float32)
+    frames = []
+    for k in range(n):
+        raw, _, _, mask = _accum_inputs(371 + k, W, H, W * s, H * s)
+        sh = np.stack([base[0] * (1 - 0.5 * k) + 0.01 * xx, base[1] * (1 - 0.5 * k) + 0.02 * yy], -1).astype(np.float32)
+        if k == 1:
+            sh[:, 200:230, 0] += 90.0      # a step of 90 LR pixels inside some tiles
+        frames.append((raw, np.ascontiguousarray(mask), np.ascontiguousarray(sh)))
+    _, oi, ow, _ = _accum_inputs(399, W, H, W * s, H * s)
+    hi0, hw0 = oi.copy(), ow.copy()
+    for raw, m, sh in frames:
+        orc.call("accumulateSuperResFull", raw, oi, ow, m, Tex(kp), Tex(sh), white, black, W, H, s, pitch_of(oi), pitch_of(m))
+    hi, hw_ = _accumulate_group_hip(hip, frames, kp, fw, fh, W, H, s, white, black, hi0, hw0, 0)
+    np.testing.assert_allclose(hw_, ow, rtol=3e-5, atol=3e-5)
+    np.testing.assert_allclose(hi, oi, rtol=3e-5, atol=3e-5)
+    assert np.abs(hw_ - hw0).max() > 0.5
+
+
 @pytest.mark.parametrize("s", [2, 4])
 def test_accumulate_anisotropic_kernels(orc, hip, s):
     """Kernel parameters as ComputeKernelParam makes them at strong edges: inverse covariances with
