@@ -609,6 +609,10 @@ int mfsr_dist_stripe_plan(const mfsr_config* cfg, int worldSize, int rank, int r
 /* *flag |= 1 (device int) if any |flow.y| of the `rows` flow rows starting at `flow` exceeds bound (NaN passes: it
  * rounds to a zero shift) */
 int mfsr_checkFlowBound(const mfsr_float2* flow, int pitch, int width, int rows, float bound, int* flag, mfsr_stream_t stream);
+/* *maxBits = max(*maxBits, bit pattern of |flow.y|) over the rows (device int, zero it first; non-negative floats order
+ * like their bit patterns; NaN is skipped): the measured vertical flow a multi-GPU caller sizes the raw-row halo of the
+ * next bursts from (mfsr_dist_measured_flow) */
+int mfsr_maxAbsFlowY(const mfsr_float2* flow, int pitch, int width, int rows, int* maxBits, mfsr_stream_t stream);
 
 /* ---- frame streams (BASELINE configs[4]): a sliding window of 2*radius+1 frames around every
  * frame, the reference's setTemporalAreaRadius(1) (finalProject/Project/multi_frame_sr.cpp:182).  Output t fuses frames
@@ -664,13 +668,17 @@ int mfsr_burst_process_source(mfsr_burst* b, const mfsr_frame_source* src, mfsr_
 int mfsr_burst_timing(mfsr_burst* b, int enable);
 int mfsr_burst_timing_read(mfsr_burst* b, double* totalMs, int* launches, int* frames);
 /* last per-frame flow field (tracking resolution, raw-pixel units) and mask,
- * for tests: returns device pointers valid until the next add_frame */
+ * for tests: returns device pointers valid until the next add_frame.  With frame-batched alignment a frame is aligned
+ * when its group is complete (or on mfsr_burst_flush / finish): while the last frame is still waiting, asking for its
+ * flow / mask returns MFSR_E_INVALID (never the previous frame's buffers) -- flush first. */
 int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2d* mask, mfsr_tex2d* kernelParam,
                            mfsr_tex2d* tracking);
-/* global pre-alignment of the last add_frame (cfg.preAlign), copied to HOST memory; synchronises the stream */
 /* products of the frame aligned `framesBack` frames before the last one (0 = the last: what mfsr_burst_debug_views gives).
- * Valid while framesBack < 2 * MFSR_MAX_FUSE_GROUP (the ring of per-frame slots) and the burst has aligned that many. */
+ * Valid while framesBack < 2 * MFSR_MAX_FUSE_GROUP (the ring of per-frame slots) and the burst has aligned that many;
+ * MFSR_E_INVALID for a frame that is still waiting for its group (see above). */
 int mfsr_burst_debug_frame_views(mfsr_burst* b, int framesBack, mfsr_tex2d* flow, mfsr_tex2d* mask);
+/* global pre-alignment of the last add_frame (cfg.preAlign), copied to HOST memory; aligns a frame that is still waiting
+ * for its group first, then synchronises the stream */
 int mfsr_burst_prealign_result(mfsr_burst* b, mfsr_prealign* hostOut, mfsr_stream_t stream);
 
 #ifdef __cplusplus

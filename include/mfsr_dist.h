@@ -11,8 +11,8 @@
  * LR-sized and are computed redundantly by every rank.  Three ways to combine:
  *
  *   MFSR_DIST_STRIPES (default)  fuse is sharded over HR row stripes: each rank sends every other rank the rows of
- *       its frames' raw / flow / certainty that the peer's stripe reads (point-to-point ncclSend/ncclRecv, one per
- *       xGMI link), then fuses ALL frames in frame order onto its own stripe, normalises it, and rank 0 collects the
+ *       its frames' raw / flow / certainty (.xyz: the fuse never reads .w) that the peer's stripe reads (point-to-point
+ *       ncclSend/ncclRecv, one per xGMI link), then fuses ALL frames in frame order onto its own stripe, normalises it, and rank 0 collects the
  *       u16 stripes.  Traffic per rank ~ N * LR * 38 B / world (0.13 GB at 4K x4, 16 frames, 8 GPUs) instead of the
  *       2.8 GB of accumulators a reduce(-scatter) moves, and the summation order is the single-GPU one: the result is
  *       BIT-IDENTICAL to the 1-GPU burst.
@@ -49,8 +49,12 @@ size_t mfsr_dist_workspace_bytes(const mfsr_config* cfg, int worldSize);
 int mfsr_dist_create(mfsr_dist** out, const mfsr_config* cfg, int rank, int worldSize, const void* id, void* workspace,
                      size_t workspaceBytes);
 void mfsr_dist_destroy(mfsr_dist* d);
-/* the burst context a mfsr_dist drives (for mfsr_burst_timing / mfsr_burst_debug_views); owned by d */
+/* the (first) burst context a mfsr_dist drives (mfsr_burst_debug_views); owned by d.  Pipelined bursts (below) alternate
+ * between two contexts: time the warp+fuse launches of a rank with mfsr_dist_timing / mfsr_dist_timing_read, which cover both
+ * (same meaning as mfsr_burst_timing / mfsr_burst_timing_read). */
 mfsr_burst* mfsr_dist_burst(mfsr_dist* d);
+int mfsr_dist_timing(mfsr_dist* d, int enable);
+int mfsr_dist_timing_read(mfsr_dist* d, double* totalMs, int* launches, int* frames);
 /* raw-row halo of the STRIPES exchange (default 64: vertical flow up to 61 raw pixels).  A halo >= the frame height
  * exchanges whole raw frames: always valid, ~2.5x the traffic (still ~9x below summing accumulators) -- the fallback
  * when mfsr_dist_process_burst reports status 1. */
@@ -60,14 +64,36 @@ int mfsr_dist_stripe(const mfsr_dist* d, int rank, int* rowBegin, int* rowEnd);
 /* One burst.  frames[k] = device pointer of frame k (dense u16) for the frames this rank owns (k mod world == rank) and
  * for the reference frame on EVERY rank; other entries are ignored.  out16: dense interleaved u16 HR image, written on
  * rank 0 only (may be NULL elsewhere).  status: device int, set to 0 / 1 on every rank: 1 = a frame's vertical flow
- * exceeded the raw halo of the STRIPES exchange (result invalid: raise the halo or use another mode). */
+ * exceeded the raw halo of the STRIPES exchange (result invalid: raise the halo or use another mode).
+ *
+ * WHEN THE OUTPUT EXISTS.  The call is asynchronous and, like mfsr_dist_wait_output, a collective: every rank makes it, in
+ * the same order.
+ *   - frames[]: read by work enqueued on `stream` only -- the buffers may be refilled once `stream` has passed this call,
+ *     as with any asynchronous call (pipelined bursts keep their own copy of the rank's frames).
+ *   - REDUCE / REDUCE_SCATTER, a world of one rank, or MFSR_DIST_PIPELINE=0: out16 / status are complete once `stream`
+ *     has passed mfsr_dist_wait_output.
+ *   - STRIPES with world > 1 (the default) runs bursts PIPELINED: call i enqueues the reference products, the alignment
+ *     and the exchange of burst i, then the fuse / finish / gather of burst i - 1, whose exchange finished while burst i
+ *     was being aligned (the caller's stream never waits for an exchange).  out16 / status of call i are therefore written
+ *     by the work that call i + 1 -- or mfsr_dist_wait_output -- enqueues: the POINTERS must stay valid and untouched until
+ *     then, and the image of burst i is complete only once `stream` has passed mfsr_dist_wait_output (last burst) or
+ *     mfsr_dist_wait_previous (burst i after call i + 1).  A device-wide synchronise after call i alone does NOT
+ *     produce image i.
+ * The transport calls go to a stream the context owns (same order on every rank), event-linked to `stream`.
+ * MFSR_DIST_OVERLAP=0 in the environment keeps every call on the caller's stream (and turns the pipelining off). */
 int mfsr_dist_process_burst(mfsr_dist* d, const uint16_t* const* frames, int mode, uint16_t* out16, int* status,
                             mfsr_stream_t stream);
-/* STRIPES mode issues its RCCL calls on a stream the context owns (same order on every rank), event-linked to `stream`:
- * the collection of burst i's stripes on rank 0 overlaps the alignment of burst i+1.  out16 / status of the LAST
- * process_burst are complete once `stream` has passed mfsr_dist_wait_output (or after a device-wide synchronise).
- * MFSR_DIST_OVERLAP=0 in the environment keeps every call on the caller's stream. */
+/* enqueues what is still owed of the last burst (pipelined: its fuse / finish / gather -- transport calls, so EVERY rank
+ * calls this, like process_burst) and makes `stream` wait for its output */
 int mfsr_dist_wait_output(mfsr_dist* d, mfsr_stream_t stream);
+/* makes `stream` wait for the newest output whose work HAS been enqueued (pipelined: burst i - 1 after call i); no
+ * transport call, not a collective, the pipeline keeps running */
+int mfsr_dist_wait_previous(mfsr_dist* d, mfsr_stream_t stream);
+/* largest |vertical flow| (raw pixels) over all frames of the newest burst whose back half has been enqueued, measured on
+ * the device and max-reduced over the ranks; waits for that burst's gather and synchronises `stream`.  A caller sizes the
+ * raw-row halo of the following bursts from it: mfsr_dist_set_raw_halo(d, ceil(v) + 3 + margin) instead of the default 64
+ * rows -- status 1 still guards every burst. */
+int mfsr_dist_measured_flow(mfsr_dist* d, float* maxAbsFlowY, mfsr_stream_t stream);
 /* "rccl" or "local": the transport behind d (see below) */
 const char* mfsr_dist_transport(const mfsr_dist* d);
 /* messages and bytes this rank SENT during the last mfsr_dist_process_burst (exchange + stripe gather; the collectives of

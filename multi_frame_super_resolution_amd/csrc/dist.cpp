@@ -68,12 +68,18 @@ inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // ---------------------------------------------------------------------------------------------------------------------
 // small device helpers of this layer (dist.cpp is compiled as HIP)
 
+// kind 0: plain copy of `bytes` bytes; kind 1: `bytes` = bytes of the float4 SOURCE texels, of which .xyz are stored densely
+// (12 B per texel); kind 2: the reverse, `bytes` = bytes of the float4 DESTINATION texels, .w := 0.  (The certainty mask's
+// .w holds the robustness kernel's M, RobustnessModell.cu:155, which no fuse kernel reads: a quarter of the mask bytes stay
+// at home.)
+enum { SEG_COPY = 0, SEG_PACK_XYZ = 1, SEG_UNPACK_XYZ = 2 };
 struct CopySeg {
     const void* src;
     void* dst;
-    unsigned long long bytes;  // multiple of 4
+    unsigned long long bytes;  // multiple of 4 (kind 1, 2: of 16)
+    int kind = SEG_COPY;
 };
-constexpr int kSegsPerLaunch = 96;  // 96 x 24 B of kernel arguments
+constexpr int kSegsPerLaunch = 96;  // 96 x 32 B of kernel arguments
 constexpr int kBlocksPerSeg = 32;
 struct CopySegs {
     CopySeg s[kSegsPerLaunch];
@@ -84,6 +90,23 @@ __global__ void __launch_bounds__(256) k_copySegments(CopySegs segs)
 {
     const CopySeg sg = segs.s[blockIdx.y];
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    if (sg.kind == SEG_PACK_XYZ) {
+        const float4* s = (const float4*)sg.src;
+        float* d = (float*)sg.dst;
+        for (size_t i = tid; i < (sg.bytes >> 4); i += nth) {
+            const float4 v = s[i];
+            d[3 * i + 0] = v.x;
+            d[3 * i + 1] = v.y;
+            d[3 * i + 2] = v.z;
+        }
+        return;
+    }
+    if (sg.kind == SEG_UNPACK_XYZ) {
+        const float* s = (const float*)sg.src;
+        float4* d = (float4*)sg.dst;
+        for (size_t i = tid; i < (sg.bytes >> 4); i += nth) d[i] = make_float4(s[3 * i + 0], s[3 * i + 1], s[3 * i + 2], 0.0f);
+        return;
+    }
     if ((((unsigned long long)sg.src | (unsigned long long)sg.dst) & 15ull) == 0) {
         const uint4* s = (const uint4*)sg.src;
         uint4* d = (uint4*)sg.dst;
@@ -104,14 +127,15 @@ __global__ void __launch_bounds__(256) k_addInPlace(float* __restrict__ a, const
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a[i] = a[i] + b[i];
 }
 
-// *v = max(*v, others[p]) for p != me
-__global__ void k_maxInts(int* v, const int* others, int world, int me)
+// v[c] = max(v[c], others[p * count + c]) for p != me
+__global__ void k_maxInts(int* v, const int* others, int world, int me, int count)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int m = *v;
+    if ((int)threadIdx.x < count && blockIdx.x == 0) {
+        const int c = threadIdx.x;
+        int m = v[c];
         for (int p = 0; p < world; p++)
-            if (p != me && others[p] > m) m = others[p];
-        *v = m;
+            if (p != me && others[p * count + c] > m) m = others[p * count + c];
+        v[c] = m;
     }
 }
 
@@ -119,7 +143,7 @@ int copy_segments(const std::vector<CopySeg>& segs, hipStream_t st)
 {
     for (size_t i = 0; i < segs.size(); i += kSegsPerLaunch) {
         CopySegs a;
-        memset(&a, 0, sizeof(a));
+        memset((void*)&a, 0, sizeof(a));
         const int n = (int)((segs.size() - i < (size_t)kSegsPerLaunch) ? segs.size() - i : kSegsPerLaunch);
         for (int j = 0; j < n; j++) a.s[j] = segs[i + j];
         hipLaunchKernelGGL(k_copySegments, dim3(kBlocksPerSeg, n), dim3(256), 0, st, a);
@@ -143,7 +167,7 @@ struct Transport {
     virtual int send(const void* buf, size_t bytes, int peer, hipStream_t st) = 0;
     virtual int recv(void* buf, size_t bytes, int peer, hipStream_t st) = 0;
     // collectives (called outside groups)
-    virtual int allReduceMaxI32(int* buf, hipStream_t st) = 0;                          // one int, in place
+    virtual int allReduceMaxI32(int* buf, int count, hipStream_t st) = 0;               // count <= 2 ints, in place
     virtual int reduceSumF32(float* buf, size_t count, int root, hipStream_t st) = 0;   // in place on root
     virtual int reduceScatterSumF32(float* buf, size_t chunk, hipStream_t st) = 0;      // buf = world chunks; mine summed in place
     // tells the peers that this rank gave up (local back end: wakes their host-side waits); no-op for RCCL
@@ -182,9 +206,9 @@ struct RcclTransport : Transport {
     {
         return nccl(ncclRecv(buf, bytes, ncclUint8, peer, comm, st), "ncclRecv");
     }
-    int allReduceMaxI32(int* buf, hipStream_t st) override
+    int allReduceMaxI32(int* buf, int count, hipStream_t st) override
     {
-        return nccl(ncclAllReduce(buf, buf, 1, ncclInt32, ncclMax, comm, st), "ncclAllReduce");
+        return nccl(ncclAllReduce(buf, buf, (size_t)count, ncclInt32, ncclMax, comm, st), "ncclAllReduce");
     }
     int reduceSumF32(float* buf, size_t count, int root, hipStream_t st) override
     {
@@ -425,19 +449,20 @@ struct LocalTransport : Transport {
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(k_addInPlace, dim3((unsigned)blocks), dim3(256), 0, st, a, b, n);
     }
-    int allReduceMaxI32(int* buf, hipStream_t st) override
+    int allReduceMaxI32(int* buf, int count, hipStream_t st) override
     {
         if (world == 1) return MFSR_OK;
+        if (count < 1 || count > 2) return fail("allReduceMaxI32: count must be 1 or 2");
         int rc = groupStart();
         if (rc != MFSR_OK) return rc;
         for (int p = 0; p < world; p++) {
             if (p == rank) continue;
-            D_KEEP(rc, send(buf, sizeof(int), p, st));
-            D_KEEP(rc, recv(iscratch + p, sizeof(int), p, st));
+            D_KEEP(rc, send(buf, sizeof(int) * count, p, st));
+            D_KEEP(rc, recv(iscratch + p * count, sizeof(int) * count, p, st));
         }
         D_KEEP(rc, groupEnd());
         if (rc != MFSR_OK) return rc;
-        hipLaunchKernelGGL(k_maxInts, dim3(1), dim3(64), 0, st, buf, (const int*)iscratch, world, rank);
+        hipLaunchKernelGGL(k_maxInts, dim3(1), dim3(64), 0, st, buf, (const int*)iscratch, world, rank, count);
         D_HIP(hipGetLastError());
         return MFSR_OK;
     }
@@ -497,7 +522,8 @@ struct DistLayout {
 // bytes of one frame's rows inside a packed message for the stripe `pl` (every piece 16-byte aligned)
 inline size_t msg_frame_bytes(const DistLayout& L, const mfsr_stripe_plan& pl)
 {
-    return up((size_t)pl.rawRows * L.W * 2, 16) + up((size_t)pl.flowRows * L.flowPitch, 16) + up((size_t)pl.maskRows * L.maskPitch, 16);
+    // (certainty rows travel as 3 of their 4 floats)
+    return up((size_t)pl.rawRows * L.W * 2, 16) + up((size_t)pl.flowRows * L.flowPitch, 16) + up((size_t)pl.maskRows * L.maskPitch / 4 * 3, 16);
 }
 inline int frames_of(int N, int rank, int world) { return rank < N ? (N - rank + world - 1) / world : 0; }
 
@@ -558,7 +584,7 @@ int make_layout(const mfsr_config* c, int world, DistLayout* L)
     L->offFlow = take(up(L->flowBytes, 256) * L->N * L->sets);
     L->offMask = take(up(L->maskBytes, 256) * L->N * L->sets);
     L->offOut16 = take(L->out16Bytes);
-    L->offFlag = take(256 + sizeof(int) * (size_t)(world > 64 ? world : 64));
+    L->offFlag = take(256 + 2 * sizeof(int) * (size_t)(world > 64 ? world : 64));
     L->offSend = take(L->sendBytes);
     L->offRecv = take(L->recvBytes);
     L->total = up(off, 256);
@@ -577,11 +603,12 @@ struct mfsr_dist {
     char* base;
     mfsr_float3 *imgOut, *totalWeights;
     uint16_t* out16;
-    int* flag;   // two ints: bursts alternate (the previous burst's all-reduce may still be in flight on the comm stream)
+    int* flag;   // three (status, max-flow bits) pairs used in turn (see process_stripes); the local transport's scratch follows at +8
     // STRIPES: every transport call goes to commStream, in the same order on every rank (exchange i, gather i, exchange i+1, ..),
     // event-linked to the caller's stream, so that the gather of burst i overlaps the alignment of burst i+1
     hipStream_t commStream;
-    hipEvent_t evAligned, evExchanged, evExchanged2, evFinished, evGathered;
+    hipEvent_t evAligned, evExchanged, evExchanged2, evFinished, evGathered, evBackStart;
+    int* lastFlag;  // (status, bits of the measured max |vertical flow|) of the last burst whose back half was enqueued
     // STRIPES, pipelined (world > 1, MFSR_DIST_PIPELINE != 0): process_burst(i) runs the reference products, the alignment and
     // the exchange of burst i, then the fuse / finish / gather of burst i - 1 -- whose exchange completed long ago -- so the
     // caller's stream never waits for an exchange; the last burst's back half runs in mfsr_dist_wait_output
@@ -637,6 +664,7 @@ static void dist_free(mfsr_dist* d)
     if (d->evExchanged2) (void)hipEventDestroy(d->evExchanged2);
     if (d->evFinished) (void)hipEventDestroy(d->evFinished);
     if (d->evGathered) (void)hipEventDestroy(d->evGathered);
+    if (d->evBackStart) (void)hipEventDestroy(d->evBackStart);
     if (d->commStream) (void)hipStreamDestroy(d->commStream);
     if (d->burst2 && d->burst2 != d->burst) mfsr_burst_destroy(d->burst2);
     if (d->burst) mfsr_burst_destroy(d->burst);
@@ -685,7 +713,17 @@ static int dist_new(mfsr_dist** out, const mfsr_config* cfg, int rank, int world
     d->overlap = (e && e[0] == '0') ? 0 : 1;
     const char* ep = getenv("MFSR_DIST_PIPELINE");
     d->pipeline = (d->L.sets > 1 && d->overlap && !(ep && ep[0] == '0')) ? 1 : 0;
-    he = hipStreamCreateWithFlags(&d->commStream, hipStreamNonBlocking);
+    {
+        // The comm stream takes the HIGHEST priority: RCCL's send / receive / reduce are kernels, and a warp+fuse launch fills
+        // every SIMD's register file (four 128-VGPR workgroups per CU) -- a transport kernel on a default-priority queue would
+        // wait for the whole launch (0.1 ms per stripe launch, 0.9 ms per whole-frame launch: the tracker launch of round 3's
+        // timeline did).  With priority its few workgroups take the first slots the retiring fuse workgroups free (one fuse
+        // workgroup lives ~30 us).  The local back end's messages are peer copies (copy engines): unaffected.
+        int lo = 0, hi = 0;
+        he = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (he == hipSuccess) he = hipStreamCreateWithPriority(&d->commStream, hipStreamNonBlocking, hi);
+    }
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&d->evBackStart, hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&d->evAligned, hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&d->evExchanged, hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&d->evExchanged2, hipEventDisableTiming);
@@ -791,6 +829,7 @@ static int exchange_rows(mfsr_dist* d, const std::vector<mfsr_stripe_plan>& plan
         if (plan[p].rowEnd > plan[p].rowBegin) {  // p fuses: it needs my frames
             const mfsr_stripe_plan& q = plan[p];
             const size_t rawB = (size_t)q.rawRows * L.W * 2, flowB = (size_t)q.flowRows * L.flowPitch, maskB = (size_t)q.maskRows * L.maskPitch;
+            const size_t maskMsg = maskB / 4 * 3;  // .xyz of every float4 texel
             sendOff[p] = so;
             char* dst = d->sendBuf() + so;
             for (int k = me; k < N; k += G) {
@@ -798,15 +837,15 @@ static int exchange_rows(mfsr_dist* d, const std::vector<mfsr_stripe_plan>& plan
                 dst += up(rawB, 16);
                 pack.push_back(CopySeg{(const char*)d->flow(k) + (size_t)q.flowRow0 * L.flowPitch, dst, flowB});
                 dst += up(flowB, 16);
-                pack.push_back(CopySeg{(const char*)d->mask(k) + (size_t)q.maskRow0 * L.maskPitch, dst, maskB});
-                dst += up(maskB, 16);
+                pack.push_back(CopySeg{(const char*)d->mask(k) + (size_t)q.maskRow0 * L.maskPitch, dst, maskB, SEG_PACK_XYZ});
+                dst += up(maskMsg, 16);
             }
             sendLen[p] = (size_t)(dst - (d->sendBuf() + so));
             so += up(sendLen[p], 256);
         }
         if (iFuse) {  // I fuse: I need p's frames
             const size_t rawB = (size_t)mine.rawRows * L.W * 2, flowB = (size_t)mine.flowRows * L.flowPitch,
-                         maskB = (size_t)mine.maskRows * L.maskPitch;
+                         maskB = (size_t)mine.maskRows * L.maskPitch, maskMsg = maskB / 4 * 3;
             recvOff[p] = ro;
             const char* src = d->recvBuf() + ro;
             for (int k = p; k < N; k += G) {
@@ -814,8 +853,8 @@ static int exchange_rows(mfsr_dist* d, const std::vector<mfsr_stripe_plan>& plan
                 src += up(rawB, 16);
                 unpack.push_back(CopySeg{src, (char*)d->flow(k) + (size_t)mine.flowRow0 * L.flowPitch, flowB});
                 src += up(flowB, 16);
-                unpack.push_back(CopySeg{src, (char*)d->mask(k) + (size_t)mine.maskRow0 * L.maskPitch, maskB});
-                src += up(maskB, 16);
+                unpack.push_back(CopySeg{src, (char*)d->mask(k) + (size_t)mine.maskRow0 * L.maskPitch, maskB, SEG_UNPACK_XYZ});
+                src += up(maskMsg, 16);
             }
             recvLen[p] = (size_t)(src - (d->recvBuf() + ro));
             ro += up(recvLen[p], 256);
@@ -862,6 +901,16 @@ static int stripes_back(mfsr_dist* d, int ctx, int rawHalo, const std::vector<co
         ~Restore() { d->cur = v; }
     } restore{d, saved};
     D_HIP(hipStreamWaitEvent(st, ctx ? d->evExchanged2 : d->evExchanged, 0));
+    // Rank 0 posts the receives of the peers' u16 stripes BEFORE its own fuse: their rows of out16 are disjoint from rank 0's
+    // stripe, so a peer that finishes first sends at once and the 7/8 of the image that come over the links (the largest term
+    // of the comm chain at configs[2]) travel while rank 0 is still fusing.  Ordered after everything the caller enqueued
+    // before this burst's back half (out16 may still be read by it) and after the previous gather (same stream B).
+    const bool earlyGather = G > 1 && me == 0 && d->overlap;
+    if (earlyGather) {
+        D_HIP(hipEventRecord(d->evBackStart, st));
+        D_HIP(hipStreamWaitEvent(B, d->evBackStart, 0));
+        D_TRY(gather_stripes(d, plan, out16, B));
+    }
     // every frame, in frame order, a group per pass over the accumulators, onto this rank's HR rows only
     if (mine.rowEnd > mine.rowBegin) {
         // (a halo that spans the whole frame needs no check: every raw row is present)
@@ -893,12 +942,13 @@ static int stripes_back(mfsr_dist* d, int ctx, int rawHalo, const std::vector<co
     D_HIP(hipEventRecord(d->evFinished, st));
     D_HIP(hipStreamWaitEvent(B, d->evFinished, 0));
     if (G > 1) {
-        D_TRY(gather_stripes(d, plan, out16, B));
-        D_TRY(d->T->allReduceMaxI32(flag, B));
+        if (!earlyGather) D_TRY(gather_stripes(d, plan, out16, B));
+        D_TRY(d->T->allReduceMaxI32(flag, 2, B));  // (status, measured max |vertical flow|)
     }
     if (status) D_HIP(hipMemcpyAsync(status, flag, sizeof(int), hipMemcpyDeviceToDevice, B));
     D_HIP(hipEventRecord(d->evGathered, B));
     d->gatherPending = true;
+    d->lastFlag = flag;
     return MFSR_OK;
 }
 
@@ -917,13 +967,15 @@ static int process_stripes(mfsr_dist* d, const uint16_t* const* frames, uint16_t
     const int N = c.frames, G = d->world, me = d->rank, ref = c.reference;
     std::vector<mfsr_stripe_plan> plan(G);
     for (int p = 0; p < G; p++) D_TRY(mfsr_dist_stripe_plan(&c, G, p, d->rawHalo, &plan[p]));
-    int* flag = d->flag + (d->burstNo & 1);
+    // (status, bits of max |vertical flow|); three pairs in turn: burst i - 3's all-reduce on the comm stream completed before
+    // the caller's stream passed the finish of burst i - 2 (it waited for that gather event there), i.e. before this memset
+    int* flag = d->flag + 2 * (d->burstNo % 3);
     d->cur = d->pipeline ? (int)(d->burstNo & 1) : 0;
     d->burstNo++;
     d->messagesSent = d->bytesSent = 0;
     // A = the caller's stream (kernels), B = the comm stream (every transport call); with overlap off B = A
     hipStream_t B = d->overlap ? d->commStream : st;
-    D_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+    D_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
 
     // front half: reference products on every rank -- what the alignment reads in full, the kernel parameters and the
     // fallback image for this rank's stripe only (nobody else reads them here) -- then this rank's frames: alignment only
@@ -945,7 +997,11 @@ static int process_stripes(mfsr_dist* d, const uint16_t* const* frames, uint16_t
                 raws[k] = d->raw(k);
                 continue;
             }
-            raws[k] = frames[k];
+            // pipelined bursts: the fuse of this burst runs during the NEXT call -- it (and the pack on the comm stream) read
+            // the library's own copy of the rank's frames, so the caller's buffers are released when `stream` has passed
+            // this call, like those of any asynchronous call (N / G frames of 2 B per pixel: ~10 us per 4K frame)
+            raws[k] = d->pipeline ? d->raw(k) : frames[k];
+            if (d->pipeline) D_HIP(hipMemcpyAsync(d->raw(k), frames[k], L.rawBytes, hipMemcpyDeviceToDevice, st));
             mineRaw.push_back(frames[k]);
             mineRef.push_back(k == ref);
             mineFlow.push_back(d->flow(k));
@@ -954,6 +1010,10 @@ static int process_stripes(mfsr_dist* d, const uint16_t* const* frames, uint16_t
         if (!mineRaw.empty())
             D_TRY(mfsr_burst_align_frames(d->ctx(), (int)mineRaw.size(), mineRaw.data(), mineRef.data(), mineFlow.data(), L.flowPitch,
                                           mineMask.data(), L.maskPitch, (mfsr_stream_t)st));
+        // the largest vertical flow of this rank's frames (every frame has one owner: the all-reduce at the end of the burst
+        // makes it the burst's): what mfsr_dist_measured_flow reports, for a caller that sizes the raw-row halo from it
+        for (size_t i = 0; i < mineFlow.size(); i++)
+            D_TRY(mfsr_maxAbsFlowY(mineFlow[i], L.flowPitch, L.tw, L.th, flag + 1, (mfsr_stream_t)st));
     }
     // exchange (on B, after the alignment on A).  (Receive buffers of this set: their last reader was the fuse of the burst two
     // calls ago, or of the previous one when bursts are not pipelined -- both are on A before the event B waits for here.)
@@ -1058,6 +1118,50 @@ extern "C" int mfsr_dist_wait_output(mfsr_dist* d, mfsr_stream_t stream)
         return rc;
     }
     if (d->gatherPending) D_HIP(hipStreamWaitEvent((hipStream_t)stream, d->evGathered, 0));
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_dist_wait_previous(mfsr_dist* d, mfsr_stream_t stream)
+{
+    D_REQUIRE(d != nullptr);
+    if (d->gatherPending) D_HIP(hipStreamWaitEvent((hipStream_t)stream, d->evGathered, 0));
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_dist_measured_flow(mfsr_dist* d, float* maxAbsFlowY, mfsr_stream_t stream)
+{
+    D_REQUIRE(d && maxAbsFlowY);
+    *maxAbsFlowY = 0.0f;
+    if (!d->lastFlag) return MFSR_OK;  // no STRIPES burst has completed its back half yet
+    if (d->gatherPending) D_HIP(hipStreamWaitEvent((hipStream_t)stream, d->evGathered, 0));
+    int bits = 0;
+    D_HIP(hipMemcpyAsync(&bits, d->lastFlag + 1, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    D_HIP(hipStreamSynchronize((hipStream_t)stream));
+    memcpy(maxAbsFlowY, &bits, sizeof(float));
+    return MFSR_OK;
+}
+
+// warp+fuse launch timing over BOTH burst contexts of a rank (pipelined bursts alternate between them)
+extern "C" int mfsr_dist_timing(mfsr_dist* d, int enable)
+{
+    D_REQUIRE(d != nullptr);
+    D_TRY(mfsr_burst_timing(d->burst, enable));
+    if (d->burst2 != d->burst) D_TRY(mfsr_burst_timing(d->burst2, enable));
+    return MFSR_OK;
+}
+
+extern "C" int mfsr_dist_timing_read(mfsr_dist* d, double* totalMs, int* launches, int* frames)
+{
+    D_REQUIRE(d && totalMs && launches && frames);
+    D_TRY(mfsr_burst_timing_read(d->burst, totalMs, launches, frames));
+    if (d->burst2 != d->burst) {
+        double ms = 0;
+        int l = 0, f = 0;
+        D_TRY(mfsr_burst_timing_read(d->burst2, &ms, &l, &f));
+        *totalMs += ms;
+        *launches += l;
+        *frames += f;
+    }
     return MFSR_OK;
 }
 

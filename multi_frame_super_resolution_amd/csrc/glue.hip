@@ -662,6 +662,30 @@ __global__ void __launch_bounds__(256) k_checkFlowBound(const float2* __restrict
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// *maxBits = max(*maxBits, bits of |flow.y|) over the rows: non-negative floats order like their bit patterns, so one
+// integer atomicMax per wavefront does; NaN is skipped (it rounds to a zero shift in the fuse kernels)
+__global__ void __launch_bounds__(256) k_maxAbsFlowY(const float2* __restrict__ flow, int pitch, int width, int rows, int* __restrict__ maxBits)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    float m = 0.0f;
+    for (int y = blockIdx.y * blockDim.y + threadIdx.y; y < rows; y += gridDim.y * blockDim.y)
+        if (x < width) {
+            const float v = fabsf(row_ptr(flow, pitch, y)[x].y);
+            if (v == v && v > m) m = v;
+        }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(maxBits, __float_as_int(m));
+}
+
+extern "C" int mfsr_maxAbsFlowY(const mfsr_float2* flow, int pitch, int width, int rows, int* maxBits, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(flow && maxBits && width > 0 && rows > 0 && (long long)pitch >= 8LL * width && (pitch & 7) == 0);
+    const int gy = mfsr_cdiv(rows, 4) < 64 ? mfsr_cdiv(rows, 4) : 64;
+    dim3 block(64, 4), grid(mfsr_cdiv(width, 64), gy);
+    hipLaunchKernelGGL(k_maxAbsFlowY, grid, block, 0, mfsr_s(stream), (const float2*)flow, pitch, width, rows, maxBits);
+    return mfsr_launch_status("maxAbsFlowY");
+}
+
 extern "C" int mfsr_checkFlowBound(const mfsr_float2* flow, int pitch, int width, int rows, float bound, int* flag,
                                    mfsr_stream_t stream)
 {

@@ -286,6 +286,7 @@ struct mfsr_burst {
     int ntensorTaps;
     Img* flowCur;  // flow of the last add_frame (raw-pixel units)
     Img* maskCur;  // certainty mask of the last add_frame
+    mfsr_prealign* preCur;  // pre-alignment estimate of the last aligned frame (cfg.preAlign; device memory)
     bool haveRef;
     bool refStale;                      // the reference's alignment products were swapped away (process_joint): finish is
                                         // still valid, aligning another frame needs a new set_reference
@@ -453,6 +454,7 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     b->ntensorTaps = mfsr_gaussin_filter_1D(cfg->sigmaTensor, b->tensorTaps);
     b->flowCur = &b->L.flowBuf[0];
     b->maskCur = &b->L.maskBuf[0];
+    b->preCur = b->L.preResult;
     b->pend.n = 0;
     b->group = mfsr_burst_group_size(&b->cfg);
     b->fresh.has = false;
@@ -468,6 +470,7 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     for (int i = 0; i < kRing; i++) {
         b->evAligned[i] = b->evFused[i] = nullptr;
         b->fusedOutstanding[i] = false;
+        b->slotFlow[i] = nullptr;
     }
     if (cfg->asyncFuse) {
         int lo = 0, hi = 0;
@@ -503,11 +506,11 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     b->heldHas = false;
     b->held.n = 0;
     b->refHost = b->refDev = nullptr;
+    b->refSlot = -1;
+    b->hostBusy = false;
     for (int i = 0; i < kMaxUploadRing + 2; i++) {
         b->evUp[i] = b->evFree[i] = nullptr;
         b->freeRecorded[i] = false;
-        b->refSlot = -1;
-        b->hostBusy = false;
     }
     if (cfg->uploadRing > 0) {
         hipError_t e = hipStreamCreateWithFlags(&b->copyStream, hipStreamNonBlocking);
@@ -726,6 +729,7 @@ static int set_reference_impl(mfsr_burst* b, const uint16_t* rawRef, int hrRow0,
     b->haveRef = true;
     b->refStale = false;
     b->framesSinceRef = 0;
+    b->holdLastGroup = false;  // (set again by every mfsr_burst_add_frame_host)
     return MFSR_OK;
 }
 
@@ -987,6 +991,7 @@ static int align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, int 
             if (!b->movPrepared)
                 TRY(mfsr_preAlignPyramid((const float*)L.movPyr[0].ptr, L.tw, L.th, L.movPyr[0].pitch, L.preMovPyr, stream));
             TRY(mfsr_preAlign(L.preRefPyr, L.preMovPyr, L.tw, L.th, c.preAlignMaxAngle, L.preWork, L.preResult, stream));
+            b->preCur = L.preResult;  // (inside align_deferred this names the frame's align set: swap_set)
             if (!c.fused) {
                 // the reference-shaped entry points take baseShift / baseRotation by value: one host round trip
                 MFSR_HIP_TRY(hipMemcpyAsync(&hostBase, L.preResult, sizeof(hostBase), hipMemcpyDeviceToHost, mfsr_s(stream)));
@@ -1299,16 +1304,23 @@ static int align_deferred(mfsr_burst* b, mfsr_stream_t stream)
     return MFSR_OK;
 }
 
-extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float3* imgOut,
-                                    mfsr_float3* totalWeights, mfsr_stream_t stream)
+// hostBurst: the frame belongs to a host-frame burst (mfsr_burst_add_frame_host), whose last groups wait for
+// mfsr_burst_finish_host; a frame added through mfsr_burst_add_frame never leaves a complete group waiting
+static int add_frame_impl(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float3* imgOut, mfsr_float3* totalWeights,
+                          bool hostBurst, mfsr_stream_t stream)
 {
     MFSR_REQUIRE(b && raw && imgOut && totalWeights);
     MFSR_REQUIRE(b->haveRef);
     MFSR_REQUIRE(!b->refStale);  // after mfsr_burst_process_joint: call mfsr_burst_set_reference first
     const mfsr_config& c = b->cfg;
     TRY(mfsr_set_cfa_pattern(c.cfa));
+    b->holdLastGroup = hostBurst;
     // G: accumulate onto the HR grid -- alone, or together with the frames that were waiting for the rest of their group
     if (b->pend.n && (b->pend.imgOut != imgOut || b->pend.totalWeights != totalWeights)) TRY(flush_pending(b, stream));
+    // a complete group was held back for mfsr_burst_finish_host and frames keep arriving (more than cfg.frames per
+    // reference, or a resident frame after a host burst): it is fused the ordinary way before this frame is registered
+    if (b->pend.n >= b->group) TRY(accumulate_pending(b, stream));
+    MFSR_REQUIRE(b->pend.n < MFSR_MAX_FUSE_GROUP);
     const int slot = b->frameCounter++ % kRing;
     Img *flow = nullptr, *mask = nullptr;
     const bool defer = can_defer_alignment(b);
@@ -1319,6 +1331,7 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
         b->maskCur = mask;
         if (b->fuseStream) MFSR_HIP_TRY(hipEventRecord(b->evAligned[slot], mfsr_s(stream)));
     }
+    if (defer) b->slotFlow[slot] = nullptr;  // (mfsr_burst_debug_frame_views: not aligned yet)
     const int i = b->pend.n++;
     b->pend.slot[i] = slot;
     b->pend.raw[i] = raw;
@@ -1332,7 +1345,8 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
     if (b->pend.n < b->group) return MFSR_OK;  // the group is fused when its last frame arrives (or on flush / finish)
     // host bursts: the group that the burst's last frame completes is fused band by band by mfsr_burst_finish_host, so that
     // finished bands of the image leave for the host while the later ones are still being fused
-    if (b->holdLastGroup && b->framesSinceRef >= c.frames) return MFSR_OK;
+    // (only the group the burst's LAST frame completes: frames beyond cfg.frames are fused as they come)
+    if (b->holdLastGroup && b->framesSinceRef == c.frames) return MFSR_OK;
     // ... and so does the group before it (MFSR_HOST_HOLD=2, the default): the first band of the image is then complete after
     // 1/8 of two groups' fuse instead of after a whole group's, and the download -- the tail of the burst -- starts that much
     // earlier; the earlier groups are fused as they arrive, under the uploads
@@ -1352,6 +1366,12 @@ extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isRe
         }
     }
     return accumulate_pending(b, stream);
+}
+
+extern "C" int mfsr_burst_add_frame(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float3* imgOut,
+                                    mfsr_float3* totalWeights, mfsr_stream_t stream)
+{
+    return add_frame_impl(b, raw, isReference, imgOut, totalWeights, false, stream);
 }
 
 extern "C" int mfsr_burst_group_size(const mfsr_config* cfg)
@@ -1643,9 +1663,8 @@ extern "C" int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw,
         const char* e = getenv("MFSR_HOST_BANDS");
         return !(e && e[0] == '0');
     }();
-    b->holdLastGroup = banded;
     if (isReference && hostRaw == b->refHost && b->refDev)
-        return mfsr_burst_add_frame(b, b->refDev, 1, imgOut, totalWeights, stream);
+        return add_frame_impl(b, b->refDev, 1, imgOut, totalWeights, banded, stream);
     const int us = b->upCounter++ % b->cfg.uploadRing;
     // a ring shorter than the fuse group: the slot may still hold a frame that waits for the rest of its group
     bool waiting = false, waitingHeld = false;
@@ -1656,7 +1675,7 @@ extern "C" int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw,
     else if (waitingHeld)
         TRY(fuse_held(b, stream));  // only the held group: the frames waiting after it keep their group
     TRY(upload_into(b, us, b->L.rawRing[us], hostRaw, stream));
-    return mfsr_burst_add_frame(b, b->L.rawRing[us], isReference, imgOut, totalWeights, stream);
+    return add_frame_impl(b, b->L.rawRing[us], isReference, imgOut, totalWeights, banded, stream);
 }
 
 // finish + download in row bands.  What is still waiting to be fused (normally the burst's last group, held back by
@@ -1849,6 +1868,9 @@ extern "C" int mfsr_burst_debug_views(mfsr_burst* b, mfsr_tex2d* flow, mfsr_tex2
                                       mfsr_tex2d* tracking)
 {
     MFSR_REQUIRE(b != nullptr);
+    // frame-batched alignment: a frame that is still waiting for its group has no flow / mask yet (flowCur / maskCur would
+    // name the previous frame's) -- the caller flushes first (mfsr_burst_flush / finish)
+    if ((flow || mask) && b->pend.n > 0 && b->pend.deferred[b->pend.n - 1]) return MFSR_E_INVALID;
     if (flow) *flow = as_tex(*b->flowCur);
     if (mask) *mask = as_tex(*b->maskCur);
     if (kernelParam) *kernelParam = as_tex(b->L.kparam4);
@@ -1870,7 +1892,8 @@ extern "C" int mfsr_burst_prealign_result(mfsr_burst* b, mfsr_prealign* hostOut,
 {
     MFSR_REQUIRE(b && hostOut);
     MFSR_REQUIRE(b->cfg.preAlign && b->L.preResult);
-    MFSR_HIP_TRY(hipMemcpyAsync(hostOut, b->L.preResult, sizeof(*hostOut), hipMemcpyDeviceToHost, mfsr_s(stream)));
+    TRY(align_deferred(b, stream));  // the last frame may still be waiting for its group: its estimate does not exist yet
+    MFSR_HIP_TRY(hipMemcpyAsync(hostOut, b->preCur, sizeof(*hostOut), hipMemcpyDeviceToHost, mfsr_s(stream)));
     MFSR_HIP_TRY(hipStreamSynchronize(mfsr_s(stream)));
     return MFSR_OK;
 }

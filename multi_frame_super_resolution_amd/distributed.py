@@ -315,12 +315,37 @@ class LocalGroup:
                 tab[r * N + k] = t.data_ptr() if t is not None else None
         return tab
 
-    def process(self, table, mode: str = "stripes"):
-        """One burst on the group's own per-rank streams; returns after every rank has enqueued it."""
-        self.D.dist_group_process_burst(self._h, table, self.MODES[mode], self.out16.data_ptr(), self._status_ptrs, None)
+    def _stream_table(self, streams):
+        if streams is None:
+            return None
+        return (self._ct.c_void_p * self.world)(*[st.cuda_stream for st in streams])
 
-    def synchronize(self):
-        self.D.dist_group_synchronize(self._h, None)
+    def process(self, table, mode: str = "stripes", out16: Optional[torch.Tensor] = None, streams=None):
+        """One burst; returns after every rank has enqueued it.  ``streams``: one torch stream per rank (default: streams the
+        group owns); ``out16``: where rank 0 collects this burst's image (default ``self.out16``) -- pipelined stripes
+        bursts write it during the NEXT call (or ``synchronize``), see include/mfsr_dist.h."""
+        dst = self.out16 if out16 is None else out16
+        self.D.dist_group_process_burst(self._h, table, self.MODES[mode], dst.data_ptr(), self._status_ptrs,
+                                        self._stream_table(streams))
+
+    def synchronize(self, streams=None):
+        self.D.dist_group_synchronize(self._h, self._stream_table(streams))
+
+    def measured_flow(self) -> float:
+        """Largest |vertical flow| (raw px) of the last burst, max over the ranks (mfsr_dist_measured_flow on rank 0)."""
+        v = self._ct.c_float(0.0)
+        with torch.cuda.device(self.devices[0]):
+            self.D.dist_measured_flow(self.rank_handle(0), self._ct.byref(v), torch.cuda.current_stream().cuda_stream)
+        return float(v.value)
+
+    def timing(self, r: int, enable: bool):
+        self.D.dist_timing(self.rank_handle(r), 1 if enable else 0)
+
+    def timing_read(self, r: int):
+        ct = self._ct
+        ms, nl, nf = ct.c_double(0), ct.c_int(0), ct.c_int(0)
+        self.D.dist_timing_read(self.rank_handle(r), ct.byref(ms), ct.byref(nl), ct.byref(nf))
+        return ms.value, nl.value, nf.value
 
     def exchange_stats(self, r: int):
         ct = self._ct

@@ -14,7 +14,7 @@ is part of the measured path.
 from __future__ import annotations
 
 import math
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -76,12 +76,15 @@ def make_burst(width: int, height: int, frames: int, scale: int = 2, mono: bool 
                device="cpu", max_shift: float = 5.0, noise: bool = True, alpha: float = 1e-4, beta: float = 1e-6,
                black: float = 256.0, white: float = 4095.0 - 256.0, shift_seed: Optional[int] = None,
                first_is_reference: bool = True,
-               angles_deg: Optional[List[float]] = None) -> Tuple[List[torch.Tensor], torch.Tensor, torch.Tensor]:
+               angles_deg: Optional[List[float]] = None,
+               keep: Optional[Sequence[int]] = None) -> Tuple[List[torch.Tensor], torch.Tensor, torch.Tensor]:
     """Returns (raw frames [H,W] int16 holding u16 bit patterns, shifts [N,2] in LR px, ground truth [3,sH,sW]).
 
     ``seed`` fixes the scene; ``shift_seed`` (default: same stream) fixes the per-frame shifts and
     noise, so ranks of a sharded burst can draw different frames of the SAME scene.  ``angles_deg`` (one per frame)
-    additionally rotates frame k about the frame centre (needs cfg.preAlign beyond a degree or two)."""
+    additionally rotates frame k about the frame centre (needs cfg.preAlign beyond a degree or two).  ``keep``: only
+    these frame numbers are rendered (the others come back as None) while the random stream advances as if all were -- a
+    rank of a sharded burst gets exactly the frames the one-GPU burst has at those positions."""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     s = scale
@@ -97,7 +100,13 @@ def make_burst(width: int, height: int, frames: int, scale: int = 2, mono: bool 
     out = []
     yy, xx = torch.meshgrid(torch.arange(height, device=device), torch.arange(width, device=device), indexing="ij")
     cfa_idx = ((yy % 2) + (xx % 2))  # RGGB: (0,0)->R=0, (0,1)/(1,0)->G=1, (1,1)->B=2
+    keep_set = None if keep is None else set(int(k) for k in keep)
     for k in range(frames):
+        if keep_set is not None and k not in keep_set:
+            if noise:  # the draw the frame would have made
+                torch.randn((3, height, width), generator=gen, device=device)
+            out.append(None)
+            continue
         tx, ty = float(shifts[k, 0]) * s, float(shifts[k, 1]) * s
         ang = float(angles_deg[k]) if angles_deg is not None else 0.0
         full = _shifted(scene, tx, ty) if ang == 0.0 else _rotated(scene, tx, ty, ang)

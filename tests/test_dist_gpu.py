@@ -197,3 +197,32 @@ def test_rccl_layer_with_one_rank(mode):
         assert torch.equal(out16, want), (mode, rep)
         out16.zero_()
     D.dist_destroy(h)
+
+
+def test_bench_child_process_path_with_a_one_rank_rccl_context():
+    """`bench.py --gpus N` as a plain command = spawn_ranks -> child processes with the launcher environment -> RCCL unique id
+    broadcast -> mfsr_dist_create -> process_burst / wait_output -> rank 0's line relayed by the parent.  The whole path with
+    N = 1 (`--spawn-ranks --force-dist`): rc 0, one JSON line, transport rccl, and the image checksum of the plain one-GPU
+    run of the same workload (the stripes mode is bit-identical)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "1080p5_gray_x2", "--no-cpu-baseline", "--no-e2e",
+              "--no-isolated"]
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common + ["--force-dist", "--spawn-ranks"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["transport"] == "rccl" and d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0
+    q = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, env=env, capture_output=True, text=True, timeout=600)
+    assert q.returncode == 0, q.stderr[-2000:]
+    e = json.loads([l for l in q.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert e["transport"] is None
+    assert d["out16_sha256_16"] == e["out16_sha256_16"] and d["out16_sha256_16"]

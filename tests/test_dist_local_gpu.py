@@ -136,6 +136,86 @@ def test_group_mode_switches_and_halo_status():
     grp.close()
 
 
+@pytest.mark.parametrize("G", [2, 3])
+def test_pipelined_bursts_release_the_callers_frames_at_return(G):
+    """Pipelined STRIPES bursts (world > 1): the fuse of burst i is enqueued by call i + 1.  include/mfsr_dist.h promises that
+    the frame buffers of call i may be refilled once the caller's stream has passed call i (the rank keeps its own copy):
+    burst A is enqueued, the ranks' streams are drained (NOT the group: that would end the pipeline), the SAME device
+    buffers are overwritten with burst B's frames, burst B is enqueued with another output image -- image A must be burst
+    A's and image B burst B's."""
+    from multi_frame_super_resolution_amd.pipeline import default_config
+    W, H, N, scale = 384, 256, 6, 2
+    dev = torch.device("cuda:0")
+    fa = [f.to(dev) for f in _burst(W, H, N, scale, False, seed=41)]
+    fb = [f.to(dev) for f in _burst(W, H, N, scale, False, seed=43)]
+    cfg = default_config(W, H, N, scale, False)
+    cfg.reference = 2
+    want_a, want_b = _single(cfg, fa, dev), _single(cfg, fb, dev)
+    assert not torch.equal(want_a, want_b)
+    live = [f.clone() for f in fa]                     # the buffers the group is given, refilled in place
+    grp, table = _group(cfg, G, live, dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(G)]
+    out_a, out_b = torch.zeros_like(want_a), torch.zeros_like(want_a)
+    torch.cuda.synchronize()
+    grp.process(table, "stripes", out16=out_a, streams=streams)
+    for st in streams:
+        st.synchronize()                               # call A's work on the callers' streams is done; its fuse is not enqueued yet
+    for dst, src in zip(live, fb):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    grp.process(table, "stripes", out16=out_b, streams=streams)
+    grp.synchronize(streams)
+    assert all(int(s.item()) == 0 for s in grp.status)
+    assert torch.equal(out_a, want_a), "image A was fused from refilled frame buffers"
+    assert torch.equal(out_b, want_b)
+    grp.close()
+
+
+def test_measured_flow_sizes_the_raw_halo():
+    """mfsr_dist_measured_flow = the largest |vertical flow| over all frames of the burst (max-reduced over the ranks): equal
+    to the maximum over the single-GPU burst's per-frame flows; a raw halo of ceil(v) + 3 rows passes the status check and
+    gives the same image, one of ceil(v) - 1 rows does not."""
+    import math
+
+    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, default_config, view_as_tensor
+    W, H, N, scale, G = 384, 256, 5, 2, 3
+    dev = torch.device("cuda:0")
+    frames = [f.to(dev) for f in _burst(W, H, N, scale, False, seed=9, max_shift=5.0)]
+    cfg = default_config(W, H, N, scale, False)
+    p = BurstPipeline(cfg, dev)
+    p.begin_burst()
+    p.set_reference(frames[0])
+    vmax = 0.0
+    for k in range(N):
+        p.add_frame(frames[k], k == 0)
+        p.flush()
+        flow_t, _, _, _ = p.debug_views()
+        vmax = max(vmax, float(view_as_tensor(flow_t, 2, dev)[..., 1].abs().max()))
+    _, want = p.finish()
+    want = want.clone()
+    p.close()
+    grp, table = _group(cfg, G, frames, dev)
+    grp.process(table, "stripes")
+    grp.synchronize()
+    v = grp.measured_flow()
+    print(f"measured max |vertical flow| {v:.4f} px (single-GPU flows: {vmax:.4f})")
+    assert abs(v - vmax) <= 1e-6 * max(1.0, vmax)
+    assert torch.equal(grp.out16, want)
+    halo = max(4, int(math.ceil(v)) + 3)
+    grp.set_raw_halo(halo)
+    grp.out16.zero_()
+    grp.process(table, "stripes")
+    grp.synchronize()
+    assert all(int(s.item()) == 0 for s in grp.status)
+    assert torch.equal(grp.out16, want)
+    if int(math.ceil(v)) - 1 >= 4:
+        grp.set_raw_halo(int(math.ceil(v)) - 1)        # covers |v| <= ceil(v) - 4: too small
+        grp.process(table, "stripes")
+        grp.synchronize()
+        assert all(int(s.item()) == 1 for s in grp.status)
+    grp.close()
+
+
 def test_group_rejects_bad_arguments_without_hanging():
     """A rank that lacks one of its frames is refused before anything is enqueued -- on every rank's worker, so nobody
     waits for a peer that gave up (the call returns an error instead of timing out)."""

@@ -1110,6 +1110,82 @@ def test_lucasKanadeIterationWarped_is_bit_identical(hip, hw, W, H):
         assert np.abs(want).max() > 0.5
 
 
+@pytest.mark.parametrize("hw,W,H,nf", [(3, 100, 70, 1), (3, 333, 141, 4), (2, 130, 90, 1), (2, 200, 77, 4), (5, 130, 90, 4), (5, 257, 131, 1),
+                                       (3, 640, 360, 4)])
+def test_lucasKanadeSweepBatch_vs_oracle_chain(orc, hw, W, H, nf):
+    """The kernel that carries Lucas-Kanade in every pipeline (k_lkSweep behind mfsr_lucasKanadeSweepBatch, fed by
+    mfsr_CreateFlowFieldWarped) DIRECTLY against the oracle's restatement of opticalFlow.cu:28-325: three chained iterations
+    of WarpingKernel -> ComputeDerivativesKernel(source = warped, target = reference) -> lucasKanadeOptim on the flow field
+    CreateFlowFieldFromTiles makes, final flow x outScale.  The two differ by libm (atan2f / cosf / sinf / sqrtf: ocml vs
+    glibc) and by the order of the window sums, amplified by 1 / sigma2 of the window's normal matrix: asserted <= 5e-4 px over
+    the well-conditioned, converged interior windows (tests/burst_compare.flow_difference_report; the measured maximum there
+    is ~1e-5), i.e. every larger difference sits in a low-sigma2 window, a border row or an unconverged flow.  Ragged strips
+    (W not a multiple of 54 lanes) and bands, h = 2, 3, 5, one and four frames per launch."""
+    import torch
+    from multi_frame_super_resolution_amd import capi
+    from tests.burst_compare import flow_difference_report
+    dev = torch.device("cuda:0")
+    r = rng(777 + W + hw)
+    base = _smooth_image(63, H + 16, W + 16)
+    ref_np = np.ascontiguousarray(base[8:8 + H, 8:8 + W])
+    ref = torch.from_numpy(ref_np).to(dev)
+    tcx, tcy = 5, 4
+    L = capi.lib()
+    shifts = [(10, 7), (6, 9), (11, 8), (7, 6)]
+    movs_np, tiles_np = [], []
+    for k in range(nf):
+        dx, dy = shifts[k]
+        movs_np.append(np.ascontiguousarray(base[dy:dy + H, dx:dx + W]))
+        true = np.array([dx - 8, dy - 8], np.float32)
+        tiles_np.append((true + r.uniform(-0.4, 0.4, (tcy, tcx, 2))).astype(np.float32))
+    # oracle: the reference's kernels one at a time
+    want = []
+    for k in range(nf):
+        flow = np.zeros((H, W, 2), np.float32)
+        orc.call("CreateFlowFieldFromTiles", flow, Tex(tiles_np[k]), 16, tcx, tcy, W, H, pitch_of(flow), F2([0, 0]), 0.0)
+        for it in range(3):
+            warped = np.zeros((H, W), np.float32)
+            Ix, Iy, Iz = (np.zeros((H, W), np.float32) for _ in range(3))
+            orc.call("WarpingKernel", W, H, pitch_of(warped), Tex(flow), warped, Tex(movs_np[k]))
+            orc.call("ComputeDerivativesKernel", W, H, pitch_of(Ix), Ix, Iy, Iz, Tex(warped), Tex(ref_np))
+            orc.call("lucasKanadeOptim", flow, Ix, Iy, Iz, pitch_of(flow), pitch_of(Ix), W, H, hw, 1e-4)
+        want.append(flow * np.float32(2.0))        # outScale of the last iteration (exact)
+    # HIP: flow field + first warp, then the sweep kernel, all frames per launch
+    movs = [torch.from_numpy(m).to(dev) for m in movs_np]
+    tiles = [torch.from_numpy(t).to(dev) for t in tiles_np]
+    f = [[torch.zeros(H, W, 2, device=dev) for _ in range(2)] for _ in range(nf)]
+    S = [[torch.full((H, W), float("nan"), device=dev) for _ in range(2)] for _ in range(nf)]
+    D = [[torch.full((H, W), float("nan"), device=dev) for _ in range(2)] for _ in range(nf)]
+    for k in range(nf):
+        L.CreateFlowFieldWarped(f[k][0].data_ptr(), capi.tex(tiles[k]), W, H, W * 8, capi.f2([0, 0]), 0.0, None, ref.data_ptr(),
+                                movs[k].data_ptr(), W * 4, S[k][0].data_ptr(), D[k][0].data_ptr(), W * 4, None)
+    for it in range(3):
+        i, o = it & 1, (it & 1) ^ 1
+        last = it == 2
+        arr = (capi.LkFrame * nf)()
+        for k in range(nf):
+            arr[k] = capi.LkFrame(f[k][i].data_ptr(), f[k][o].data_ptr(), movs[k].data_ptr(), S[k][i].data_ptr(), D[k][i].data_ptr(),
+                                  None if last else S[k][o].data_ptr(), None if last else D[k][o].data_ptr())
+        L.lucasKanadeSweepBatch(nf, arr, ref.data_ptr(), W * 8, W * 4, W * 4, W, H, hw, 1e-4, 2.0 if last else 1.0, None)
+    torch.cuda.synchronize()
+    for k in range(nf):
+        got = f[k][1].cpu().numpy()
+        assert np.isfinite(got).all()
+        rep = flow_difference_report(got / 2.0, want[k] / 2.0, ref_np, hw, thr=5e-4)
+        d = np.abs(got - want[k]) / 2.0
+        true = np.array([shifts[k][0] - 8, shifts[k][1] - 8], np.float32)
+        err = np.abs(got[12:-12, 12:-12] / 2.0 - true).mean()
+        print(f"h={hw} {W}x{H} frame {k}/{nf}: |flow(k_lkSweep) - flow(oracle chain)| well-conditioned windows ({rep['well_fraction']:.0%}) max "
+              f"{rep['max_well']:.2e} px, rest max {rep['max_rest']:.2e} px, median {np.median(d):.1e}, > 5e-4: {rep['n_big']} "
+              f"({rep['big_in_rest_fraction']:.0%} of them in the rest); mean distance to the true shift {err:.3f} px")
+        assert rep["well_fraction"] >= 0.3                     # the classification is not vacuous
+        assert rep["max_well"] <= 5e-4                         # ... and every larger difference is in the rest
+        assert np.median(d) <= 2e-5
+        assert err < 0.25                                      # both converged on the translation
+        # the h-px ring keeps the input flow (x outScale on the last iteration is applied to it as well in both)
+        np.testing.assert_allclose(got[:hw], want[k][:hw], rtol=0, atol=1e-6)
+
+
 @pytest.mark.parametrize("hw,W,H,nf", [(3, 100, 70, 1), (3, 333, 141, 3), (2, 64, 40, 2), (5, 130, 90, 4), (3, 1920, 1080, 4), (3, 1920, 1080, 1)])
 def test_lucasKanadeSweepBatch_matches_the_tile_kernel(hip, hw, W, H, nf):
     """mfsr_lucasKanadeSweepBatch (k_lkSweep: register / DPP column sweep, several frames per launch) against
@@ -1167,8 +1243,14 @@ def test_lucasKanadeSweepBatch_matches_the_tile_kernel(hip, hw, W, H, nf):
         assert np.abs(want[k]).max() > 0.5
         if hw >= 3:
             # windows whose smaller singular value is tiny amplify the last-bit differences of the sums (the same windows in
-            # which either kernel differs from the three-kernel chain and from the oracle)
-            assert np.median(d) <= 5e-6 and np.percentile(d, 99) <= 1.5e-4 and np.mean(d > 1e-3) <= 1e-4 and d.max() < 2e-2
+            # which either kernel differs from the three-kernel chain and from the oracle): classified, not excused by a
+            # loose maximum -- over the well-conditioned interior windows the two kernels agree to 5e-4 px (they do to ~1e-5),
+            # so every larger difference sits in a low-sigma2 window, a border row or an unconverged flow
+            from tests.burst_compare import flow_difference_report
+            rep = flow_difference_report(got[k] / 2.0, want[k] / 2.0, ref.cpu().numpy(), hw, thr=5e-4)
+            print(f"   well-conditioned windows ({rep['well_fraction']:.0%}): max {rep['max_well']:.2e} px; rest: max {rep['max_rest']:.2e} px")
+            assert np.median(d) <= 5e-6 and np.percentile(d, 99) <= 1.5e-4 and np.mean(d > 1e-3) <= 1e-4
+            assert rep["max_well"] <= 5e-4 and rep["well_fraction"] >= 0.3
         else:
             assert np.mean(d > 1e-4) < 2e-2
     if W >= 1920:
