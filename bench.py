@@ -47,7 +47,8 @@ WORKLOADS = {
     "4k16_rggb_x2": (3840, 2160, 16, 2, False),      # BASELINE configs[2]
     "1080p5_gray_x2": (1920, 1080, 5, 2, True),      # BASELINE configs[1]
     "4k16_rggb_x4": (3840, 2160, 16, 4, False),      # BASELINE configs[3] (per GPU)
-    "8k8_rggb_x2": (7680, 4320, 8, 2, False),        # BASELINE configs[4]: 64-frame 8K burst = 8 frames per GPU at N = 8
+    "8k8_rggb_x2": (7680, 4320, 8, 2, False),        # BASELINE configs[4]'s per-GPU share at N = 8 (8 of the 64 frames)
+    "8k64_rggb_x2": (7680, 4320, 64, 2, False),      # BASELINE configs[4] as stated: the 64-frame 8K burst (4.2 GB of raw frames)
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_CLOCK_GHZ = 2.4    # MI355X peak engine clock
@@ -682,11 +683,21 @@ def main():
         k_ms = tot_ms.value / max(launches.value, 1)
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         achieved_ref = bytes_ref_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic, valu = None, None
+        traffic, valu, traffic_note = None, None, None
         tpath = os.path.join(ROOT, "profiles", "fuse_traffic.json")
         if os.path.exists(tpath):
             try:
                 ent = json.load(open(tpath)).get(args.workload)
+                # the counters describe one state of the kernel sources: an entry taken from another state is not reported
+                import hashlib
+                hsh = hashlib.sha256()
+                for f in ("accumulate_fast.hip", "accumulate_common.hpp"):
+                    hsh.update(open(os.path.join(ROOT, "multi_frame_super_resolution_amd", "csrc", f), "rb").read())
+                if isinstance(ent, dict) and ent.get("kernel_source_sha16") != hsh.hexdigest()[:16]:
+                    traffic_note = ("profiles/fuse_traffic.json was measured on another state of accumulate_fast.hip / accumulate_common.hpp "
+                                    f"(stamp {ent.get('kernel_source_sha16')}, sources {hsh.hexdigest()[:16]}): traffic and the VALU floor are not "
+                                    "reported; refresh with tools/gpu_pmc_workloads.sh")
+                    ent = None
                 # the counters were taken on whole-frame launches of one grouping: they say nothing about a stripe-sharded
                 # run (row_frac < 1) or another --group
                 if isinstance(ent, dict) and (row_frac != 1.0 or (ent.get("frames_per_launch") is not None and
@@ -698,9 +709,19 @@ def main():
                     if vi:
                         # VALU-issue ceiling: every wave-level VALU instruction occupies its SIMD for 4 cycles (wave64 on a
                         # 16-lane SIMD); 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock
-                        floor_ms = vi * 4 / (1024 * VALU_CLOCK_GHZ * 1e9) * 1e3
-                        valu = {"wave_insts_per_launch": vi, "cycles_per_inst": 4, "simds": 1024, "clock_ghz": VALU_CLOCK_GHZ,
+                        # nominal: 4 cycles per wave-instruction.  Measured (tools/ubench/valu_ops.hip): 2.8 cycles for the
+                        # fast class, 4.4 for the slow one, 8.3 for transcendentals -- the static mix of this kernel
+                        # (tools/valu_mix.py) prices its stream at cpw cycles per instruction: the floor a launch can reach
+                        cpw = ent.get("cycles_per_inst_weighted")
+                        nominal_ms = vi * 4 / (1024 * VALU_CLOCK_GHZ * 1e9) * 1e3
+                        floor_ms = vi * (cpw or 4) / (1024 * VALU_CLOCK_GHZ * 1e9) * 1e3
+                        valu = {"wave_insts_per_launch": vi, "cycles_per_inst": cpw or 4, "simds": 1024, "clock_ghz": VALU_CLOCK_GHZ,
                                 "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / k_ms, 4) if k_ms > 0 else None,
+                                "cycles_per_inst_note": ("class-weighted issue cost of the kernel's static instruction mix "
+                                                         f"({ent.get('valu_mix_static')}; fast 2.8 / slow 4.4 / transcendental 8.3 cycles, "
+                                                         "tools/ubench/valu_ops.hip)") if cpw else "nominal 4 cycles (no instruction mix recorded)",
+                                "nominal_4_cycles": {"floor_ms": round(nominal_ms, 4),
+                                                     "frac": round(nominal_ms / k_ms, 4) if k_ms > 0 else None},
                                 "source": ent.get("source")}
                 elif ent is not None:
                     traffic = ent
@@ -726,7 +747,7 @@ def main():
                                    ", frames resident in HBM"),
             "config": {
                 "workload": f"{n_frames}-frame {W}x{H} {'gray' if mono else 'RGGB u16'} burst -> x{s} "
-                            f"({args.workload}; BASELINE configs[{ {'4k16_rggb_x2': 2, '1080p5_gray_x2': 1, '4k16_rggb_x4': 3, '8k8_rggb_x2': 4}[args.workload] }])",
+                            f"({args.workload}; BASELINE configs[{ {'4k16_rggb_x2': 2, '1080p5_gray_x2': 1, '4k16_rggb_x4': 3, '8k8_rggb_x2': 4, '8k64_rggb_x2': 4}[args.workload] }])",
                 "frames_per_gpu": len(mine),
                 "burst_frames": n_frames,
                 "output_mpix_per_s": round(s * s * W * H * args.steps / dt / 1e6, 2),
@@ -760,6 +781,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
+                **({"traffic_note": traffic_note} if traffic_note else {}),
                 "bytes_per_launch": int(bytes_launch),
                 "bytes_note": "algorithmic bytes a launch must move: both accumulator plane-sets once (HR*48 B; HR*24 B on the "
                               "first launch of a burst, which overwrites them), the kernel-parameter field once, raw + flow + "

@@ -8,9 +8,47 @@ WRITE_SIZE * 1024 (the fetch counter sees half of the read traffic on this part)
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import re
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FUSE_SOURCES = ["multi_frame_super_resolution_amd/csrc/accumulate_fast.hip", "multi_frame_super_resolution_amd/csrc/accumulate_common.hpp"]
+
+
+def fuse_source_sha16():
+    """stamp of the kernel sources the counters describe: bench.py reports traffic / the VALU floor only while it matches"""
+    h = hashlib.sha256()
+    for f in FUSE_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# the kernel instance each workload's group launches run (static instruction mix: tools/valu_mix.py)
+MIX_KERNEL = {"4k16_rggb_x2": "k_accumulate2xTileILi148ELi4ELi4E", "8k8_rggb_x2": "k_accumulate2xTileILi148ELi4ELi4E",
+              "8k64_rggb_x2": "k_accumulate2xTileILi148ELi4ELi4E", "4k16_rggb_x4": "k_accumulate4xTileILi148ELi4E",
+              "1080p5_gray_x2": "k_accumulate2xTileILi85ELi2ELi2E"}
+
+
+def static_mix(names):
+    out = {}
+    try:
+        txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_mix.py"), FUSE_SOURCES[0], "|".join(sorted(set(names)))],
+                             capture_output=True, text=True, timeout=900).stdout
+        cur = None
+        for ln in txt.splitlines():
+            if ln.startswith("_Z"):
+                cur = ln.strip()
+            elif ln.strip().startswith("{") and cur:
+                for n in names:
+                    if n in cur:
+                        out[n] = json.loads(ln.strip())
+    except Exception as e:   # the summary must not depend on the compiler being there
+        print("valu_mix failed:", e)
+    return out
 
 root, wls = sys.argv[1], sys.argv[2:]
 res, lines = {}, []
@@ -45,11 +83,19 @@ for wl in wls:
     except Exception:
         fpl = None
     res[wl] = {"hbm_bytes_per_launch": int(hbm), "valu_wave_insts_per_launch": int(valu), "frames_per_launch": fpl,
+               "kernel_source_sha16": fuse_source_sha16(),
                "source": f"rocprofv3 --pmc passes of tools/gpu_pmc_workloads.sh ({kname}: {n_main} dispatches + "
                          f"{n_margin} margin dispatches per burst)"}
     lines.append(f"{wl}: kernel {k[:90]}")
     lines.append(f"  dispatches per burst: {n_main} (+{n_margin} margin); per launch: FETCH_SIZE {fetch:.0f} KB, WRITE_SIZE {write:.0f} KB, "
                  f"HBM bytes (2*F+W) {hbm / 1e9:.3f} GB, SQ_INSTS_VALU {valu:.4g}, waves {per_launch('SQ_WAVES'):.0f}")
+mix = static_mix([MIX_KERNEL[w] for w in res if w in MIX_KERNEL])
+for wl in res:
+    m = mix.get(MIX_KERNEL.get(wl, ""))
+    if m:
+        res[wl]["cycles_per_inst_weighted"] = m["cycles_per_inst_weighted"]
+        res[wl]["valu_mix_static"] = m["mix"]
+        lines.append(f"{wl}: static VALU mix of {MIX_KERNEL[wl]}: {m['mix']} -> {m['cycles_per_inst_weighted']} cycles per instruction (nominal 4)")
 open(f"{root}/summary.txt", "w").write("\n".join(lines) + "\n")
 json.dump(res, open(f"{root}/fuse_traffic.json", "w"), indent=1)
 print("\n".join(lines))
