@@ -1136,7 +1136,7 @@ def test_lucasKanadeSweepBatch_vs_oracle_chain(orc, hw, W, H, nf):
     for k in range(nf):
         dx, dy = shifts[k]
         movs_np.append(np.ascontiguousarray(base[dy:dy + H, dx:dx + W]))
-        true = np.array([dx - 8, dy - 8], np.float32)
+        true = np.array([8 - dx, 8 - dy], np.float32)        # ref(p) = moved(p + u): u = -(offset of the moved crop)
         tiles_np.append((true + r.uniform(-0.4, 0.4, (tcy, tcx, 2))).astype(np.float32))
     # oracle: the reference's kernels one at a time
     want = []
@@ -1173,7 +1173,7 @@ def test_lucasKanadeSweepBatch_vs_oracle_chain(orc, hw, W, H, nf):
         assert np.isfinite(got).all()
         rep = flow_difference_report(got / 2.0, want[k] / 2.0, ref_np, hw, thr=5e-4)
         d = np.abs(got - want[k]) / 2.0
-        true = np.array([shifts[k][0] - 8, shifts[k][1] - 8], np.float32)
+        true = np.array([8 - shifts[k][0], 8 - shifts[k][1]], np.float32)
         err = np.abs(got[12:-12, 12:-12] / 2.0 - true).mean()
         print(f"h={hw} {W}x{H} frame {k}/{nf}: |flow(k_lkSweep) - flow(oracle chain)| well-conditioned windows ({rep['well_fraction']:.0%}) max "
               f"{rep['max_well']:.2e} px, rest max {rep['max_rest']:.2e} px, median {np.median(d):.1e}, > 5e-4: {rep['n_big']} "
