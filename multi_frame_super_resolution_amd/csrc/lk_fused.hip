@@ -476,32 +476,23 @@ extern "C" int mfsr_CreateFlowFieldWarpedBatch(int nFrames, const mfsr_flowfield
                                   pitchImg, pitchSD, stream);
 }
 
-// ---- the same iteration as a register column sweep, for up to MFSR_LK_MAX_BATCH frames per launch -----------------------------
+// ---- the same iteration as a register / DPP column sweep, for up to MFSR_LK_MAX_BATCH frames per launch -----------------------
 // k_lkIterationFused spends most of its ~430 VALU instructions per pixel around the arithmetic: a 32 x 16 tile stages
 // (32+10) x (16+10) samples (2.1x), forms the products on (32+6) x (16+6) (1.6x), moves everything through LDS with
 // index arithmetic for every element and crosses three barriers.  Here ONE WAVEFRONT owns 64 image columns and sweeps
-// down a band of rows, one image row per step, with no LDS memory and no barrier:
+// down a band of rows, one image row per step, with no LDS and no barrier:
 //   * vertical state lives in registers of the lane that owns the column: the last five rows of (warped + ref) for the
-//     y derivative and a ring of 2h+1 row sums per product (the row loop is unrolled over the ring, so the ring index is a
-//     compile-time register name);
-//   * horizontal neighbours come through the LDS crossbar, ds_bpermute_b32 (no LDS memory is touched): lane l reads lane
-//     l - n.  Round 3 used the GFX9 whole-wave DPP shift (v_add_f32_dpp wave_shr:1, Horner-style, 2h per product: 30 per
-//     row at h = 3) -- those issue at 5 cycles against 2.8 for a plain add (tools/ubench/dpp_wave_shift.hip) and were a
-//     fifth of the kernel's issue time while its LDS pipe sat idle.  Now the (2h+1)-wide row sum is a TREE over shifted
-//     partial sums (pairs, quads, ...: 4 permutes + 4 plain adds per product at h = 3 instead of 6 DPP adds), the
-//     x-derivative's four neighbours are four permutes.  Lane l ends with the sum of lanes l-2h .. l, i.e. the window
-//     centred on column l - h, which is the pixel that lane then owns for the solve, the flow update and the warp that
-//     makes the next iteration's input;
-//   * the (2h+1)-row column sum is a van Herk / Gil-Werman running sum over blocks of 2h+1 rows instead of 2h adds per row
-//     and product: within a block the rows add into a prefix (1 add), at the end of a block the ring is turned in place
-//     into suffix sums (2h adds per block), a window = suffix of the previous block + prefix of this one (1 add): ~2.7
-//     adds per row and product instead of 7.  Blocks are aligned to ABSOLUTE rows (the band height is a multiple of
-//     2h+1), so the order in which a pixel's window is summed depends on its row only -- not on the band or on how many
-//     frames share the launch: a frame's flow is the same bits in every batch;
+//     y derivative, the last 2h+1 rows of the five row-summed products (a ring the row loop is unrolled over, so the ring
+//     index is a compile-time register name);
+//   * horizontal neighbours come through the GFX9 whole-wave DPP shifts: Ix from wave_shl:1 / wave_shr:1 moves, the
+//     2h+1-wide row sums Horner-style -- acc = v + wave_shr:1(acc), 2h times: ONE v_add_f32_dpp per step, so lane l ends
+//     with the sum of lanes l-2h .. l, i.e. the window centred on column l - h, which is the pixel that lane then owns
+//     for the solve, the flow update and the warp that makes the next iteration's input (tools/ubench/dpp_wave_shift.hip
+//     checks the shifts on the hardware: 2.1 ns per wave-instruction, against 1.2 for a plain add);
 //   * of 64 lanes 64 - 2(h+2) produce a pixel (84 % at h = 3); a band of R rows reads R + 2(h+2) rows.
-// Same products and the same solve / update / warp code as k_lkIterationFused<PRE>; the window sums add in another order
-// (tree across, prefix + suffix down), so the flow agrees with it -- and with the oracle's chain -- to fp32 rounding
-// amplified by 1 / sigma2 of the window (tests: test_lucasKanadeSweepBatch_vs_oracle_chain).
+// Same products, same column-sum order (top to bottom) and the same solve / update / warp code as k_lkIterationFused<PRE>;
+// the row sums add right to left instead of in the four-neighbour tree, so the flow agrees with it to fp32 rounding
+// (<= 1e-5 px on the tests), like every other summation order of this stage (header of this file).
 #define MFSR_LK_SWEEP_MAX_BATCH 4
 struct LkSweepFrame {
     const float2* flowIn;
@@ -516,28 +507,13 @@ struct LkSweepBatch {
     LkSweepFrame f[MFSR_LK_SWEEP_MAX_BATCH];
 };
 
-// lane l <- lane (l - n) mod 64 through the LDS crossbar: `addr` = 4 * (l - n), made once per kernel.  (Lanes whose source
-// wraps around receive a value from the other end of the wave: they are never output lanes, see outLane.)
-__device__ __forceinline__ float lk_perm(int addr, float v)
+__device__ __forceinline__ float lk_wshr1(float v)  // lane l <- lane l-1 (lane 0 <- 0)
 {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x138, 0xf, 0xf, true));
 }
-
-// sum of lanes l - 2h .. l of v, as a tree over shifted partial sums; A[n] = bpermute address of lane l - n
-template <int HT>
-__device__ __forceinline__ float lk_row_sum(const int (&A)[16], float v)
+__device__ __forceinline__ float lk_wshl1(float v)  // lane l <- lane l+1 (lane 63 <- 0)
 {
-    constexpr int WIN = 2 * HT + 1;
-    const float t2 = v + lk_perm(A[1], v);                       // lanes l-1 .. l
-    if (WIN == 3) return t2 + lk_perm(A[2], v);
-    const float t4 = t2 + lk_perm(A[2], t2);                     // l-3 .. l
-    if (WIN == 5) return t4 + lk_perm(A[4], v);
-    if (WIN == 7) return (t4 + lk_perm(A[4], t2)) + lk_perm(A[6], v);
-    const float t8 = t4 + lk_perm(A[4], t4);                     // l-7 .. l
-    if (WIN == 9) return t8 + lk_perm(A[8], v);
-    if (WIN == 11) return (t8 + lk_perm(A[8], t2)) + lk_perm(A[10], v);
-    if (WIN == 13) return (t8 + lk_perm(A[8], t4)) + lk_perm(A[12], v);
-    return ((t8 + lk_perm(A[8], t4)) + lk_perm(A[12], t2)) + lk_perm(A[14], v);   // WIN == 15
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x130, 0xf, 0xf, true));
 }
 
 // the warp of lk_warp_sample in two phases, so that the gather a pixel issues after its flow update is consumed one row
@@ -598,20 +574,11 @@ __global__ void __launch_bounds__(64)
 
     float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;     // (warped + ref) of rows r-4 .. r
     float d0 = 0, d1 = 0, d2 = 0;                     // (warped - ref) of rows r-2 .. r
-    // ring over the rows of a block of WIN rows: slot j = this block's row sum once step j has run, the PREVIOUS block's
-    // suffix sum (rows j .. WIN-1 of it) until then; pre = sum of this block's rows so far
-    float H[5][WIN], pre[5];
+    float H[5][WIN];                                  // row sums of the five products, ring over rows
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        pre[k] = 0.0f;
+    for (int k = 0; k < 5; k++)
 #pragma unroll
         for (int j = 0; j < WIN; j++) H[k][j] = 0.0f;
-    }
-    // ds_bpermute addresses: A[n] = lane l - n, Ap1 / Ap2 = lanes l + 1 / l + 2
-    int A[16];
-#pragma unroll
-    for (int n = 0; n < 16; n++) A[n] = 4 * (lane - n);
-    const int Ap1 = 4 * (lane + 1), Ap2 = 4 * (lane + 2);
 
     auto load_row = [&](int t, float& sv, float& dv) {
         const int gy = lk_mirror_index(ry0 - HALO + t, height);
@@ -650,7 +617,7 @@ __global__ void __launch_bounds__(64)
             float2 shift = row_ptr(F.flowIn, pitchShift, yc)[colOutC];
             const float rvOwn = row_ptr(refImg, pitchImg, yc)[colOutC];
             // products of image row r - 2 (opticalFlow.cu:116-131 on the sum image, as k_lkIterationFused step 2)
-            const float xp1 = lk_perm(Ap1, s2), xp2 = lk_perm(Ap2, s2), xm1 = lk_perm(A[1], s2), xm2 = lk_perm(A[2], s2);
+            const float xp1 = lk_wshl1(s2), xp2 = lk_wshl1(xp1), xm1 = lk_wshr1(s2), xm2 = lk_wshr1(xm1);
             float tx = xp2;
             tx -= xp1 * 8.0f;
             tx += xm1 * 8.0f;
@@ -662,22 +629,25 @@ __global__ void __launch_bounds__(64)
             ty -= s0;
             const float Iy = ty * (1.0f / 24.0f);
             const float It = d0;
-            const float P[5] = {Ix * Ix, Ix * Iy, Iy * Iy, Ix * It, Iy * It};
-            // row sums (lane l <- lanes l - 2h .. l), then the column sum of the window that ends on this row: the previous
-            // block's suffix from slot j + 1 plus this block's prefix
+            float P[5] = {Ix * Ix, Ix * Iy, Iy * Iy, Ix * It, Iy * It};
+            // row sums: lane l <- lanes l - 2h .. l
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                float acc = P[k];
+#pragma unroll
+                for (int q = 0; q < 2 * HT; q++) acc = P[k] + lk_wshr1(acc);
+                H[k][j] = acc;
+            }
+            if (t < 2 * HALO) continue;   // the ring holds fewer than 2h+1 rows of this band yet
+            // column sums, top row first: the ring's oldest entry is slot j + 1
             float V[5];
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                const float hn = lk_row_sum<HT>(A, P[k]);
-                pre[k] = j == 0 ? hn : pre[k] + hn;
-                V[k] = j < WIN - 1 ? H[k][(j + 1) % WIN] + pre[k] : pre[k];
-                H[k][j] = hn;
-                if (j == WIN - 1) {   // end of the block: the ring becomes suffix sums, in place (slot 0 is never read as one)
+                float sum = 0;
 #pragma unroll
-                    for (int i = WIN - 2; i >= 1; i--) H[k][i] += H[k][i + 1];
-                }
+                for (int d = 1; d <= WIN; d++) sum += H[k][(j + d) % WIN];
+                V[k] = sum;
             }
-            if (t < 2 * HALO) continue;   // fewer than 2h+1 rows of this band have been summed yet
             if (!(ringCol || y < h || y >= height - h)) {
                 float inv[4];
                 if (lk_pinv(V[0], V[1], V[2], minDet, inv)) {
@@ -729,14 +699,10 @@ extern "C" int mfsr_lucasKanadeSweepBatch(int nFrames, const mfsr_lk_frame* fram
     }();
     // (measured at 1920 x 1080, h = 3: one frame 27.0 / 32.5 / 48.8 us with bands of 8 / 16 / 32 rows, four frames 27.1 / 26.5 /
     // 27.6 us per frame: the wave count decides, the halo rows cost less than idle SIMDs)
-    // The band height is a multiple of the window height 2h+1: the blocks of the running column sum (k_lkSweep) then start
-    // on the same absolute rows in every band, so a frame's flow does not depend on the band height (i.e. on the batch).
-    const int WIN = 2 * h + 1;
     int band = (int)((long long)height * strips * nFrames / 8192);
-    band = (band + WIN / 2) / WIN * WIN;
-    band = band < WIN ? WIN : (band > 9 * WIN ? 9 * WIN : band);
-    if (band < 6 && WIN < 6) band = 2 * WIN;   // (h = 1, 2: at least 6 rows per band)
-    if (forceBand >= 1) band = (forceBand + WIN - 1) / WIN * WIN;
+    band = (band + 4) & ~7;
+    band = band < 8 ? 8 : (band > 64 ? 64 : band);
+    if (forceBand >= 8) band = forceBand;
     dim3 grid(strips, mfsr_cdiv(height, band), nFrames), block(64);
 #define LKS_CASE(HT)                                                                                                          \
     case HT:                                                                                                                  \
