@@ -76,26 +76,36 @@ __device__ __forceinline__ bool psd_ok(float kx, float ky, float kz)
 }
 
 // Finish epilogue of the tile kernels (the burst's LAST warp+fuse launch): the strip's four pixels are normalised straight
-// from their staged sums -- H1 + H2 + quantisation through finish_value, the code k_finishFused runs, so the bits are
-// those of the separate pass -- and the finished image leaves with the accumulators: the finish pass (HR x 24 B read again)
-// disappears.  fin.width == 0: no epilogue.  myP / myW: the strip's 12 + 12 staged floats (value sums, weight sums).
-__device__ __forceinline__ void finish_strip(const FinishArgs& fin, int X0, int Y, const float* myP, const float* myW)
+// from their staged sums -- H1 + H2 + quantisation through the functions k_finishFused runs (finish_common.hpp), so the
+// bits are those of the separate pass -- and the finished image leaves with the accumulators: the finish pass (HR x 24 B
+// read again) disappears.  myP / myW: the strip's 12 + 12 staged floats (value sums, weight sums); myP is overwritten with
+// the finished values (its sums have been written back by then).
+// Code size matters here: the pixel bodies before it are ~55 KB of straight-line code for a 64 KB instruction cache, so
+// the epilogue is ROLLED loops -- one copy of the weighting (three IEEE divisions, the rare fallback resample) for the four
+// pixels, one copy of powf for the twelve channel values -- with the finished values parked in LDS between the phases.
+// (Unrolled, with twelve inlined powf, it was 3 000 instructions and made the launch 0.38 ms slower.)
+__device__ __forceinline__ void finish_strip(const FinishArgs& fin, int X0, int Y, float* myP, const float* myW)
 {
-    float o[12];
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < 4; k++) {
         const pix3 val = {myP[3 * k], myP[3 * k + 1], myP[3 * k + 2]};
         const pix3 w = {myW[3 * k], myW[3 * k + 1], myW[3 * k + 2]};
-        const pix3 r = finish_value(fin, X0 + k, Y, val, w);
-        o[3 * k] = r.x, o[3 * k + 1] = r.y, o[3 * k + 2] = r.z;
+        const pix3 r = finish_weighted(fin, X0 + k, Y, val, w);
+        myP[3 * k] = r.x, myP[3 * k + 1] = r.y, myP[3 * k + 2] = r.z;
     }
+    if (fin.applyGamma) {
+#pragma unroll 1
+        for (int i = 0; i < 12; i++) myP[i] = gamma_f(myP[i]);
+    }
+    const float4 o0 = ((const float4*)myP)[0], o1 = ((const float4*)myP)[1], o2 = ((const float4*)myP)[2];
     if (fin.outImg) {   // 48 contiguous bytes, 16-byte aligned (X0 is a multiple of 4; pitch and base checked on the host)
         float4* d = (float4*)((char*)fin.outImg + (size_t)Y * fin.outPitch + (size_t)X0 * 12);
-        d[0] = make_float4(o[0], o[1], o[2], o[3]);
-        d[1] = make_float4(o[4], o[5], o[6], o[7]);
-        d[2] = make_float4(o[8], o[9], o[10], o[11]);
+        d[0] = o0;
+        d[1] = o1;
+        d[2] = o2;
     }
     if (fin.out16) {    // 24 contiguous bytes, 8-byte aligned
+        const float o[12] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y, o2.z, o2.w};
         uint32_t q[6];
 #pragma unroll
         for (int i = 0; i < 6; i++)
@@ -1201,7 +1211,7 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
         // the burst's last launch: this lane's four pixels, finished (the side-margin strips and the margin rows belong to
         // the margin kernel, whose pixels the host finishes after it)
         if constexpr (FIN) {
-            if (stripLive) finish_strip(fin, X0, Y, (const float*)&sAcc[0][ly][0] + lx * 12, (const float*)&sAcc[1][ly][0] + lx * 12);
+            if (stripLive) finish_strip(fin, X0, Y, (float*)&sAcc[0][ly][0] + lx * 12, (const float*)&sAcc[1][ly][0] + lx * 12);
         }
     } else {
         if (!valueSumsStaged) add_plane(0, accP);
@@ -1652,7 +1662,10 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : ((NF) > 2 && TILE_LDS_ALI
         }
     }
     if constexpr (FIN) {
-        if (stripLive) finish_strip(fin, X0, Y, myP, myW);  // the burst's last launch (see k_accumulate2xTile)
+        // the burst's last launch (see k_accumulate2xTile).  The epilogue overwrites the strip's staged value sums, which
+        // the OTHER wave of the row reads in its write-back above: both must be past it
+        __syncthreads();
+        if (stripLive) finish_strip(fin, X0, Y, myP, myW);
     }
 }
 

@@ -61,8 +61,8 @@ struct FinishArgs {
     uint16_t* out16;
 };
 
-// finished value of pixel (x, yFull) of the full image from its accumulated value `val` and weight `w`
-__device__ __forceinline__ pix3 finish_value(const FinishArgs& f, int x, int yFull, pix3 val, pix3 w)
+// H1 of pixel (x, yFull) of the full image from its accumulated value `val` and weight `w` (before the gamma)
+__device__ __forceinline__ pix3 finish_weighted(const FinishArgs& f, int x, int yFull, pix3 val, pix3 w)
 {
     pix3 inout = {0.0f, 0.0f, 0.0f};
     // ApplyWeighting reads the fallback only where a weight is under the threshold (kernel.cu:444-462): the resample (12
@@ -75,6 +75,13 @@ __device__ __forceinline__ pix3 finish_value(const FinishArgs& f, int x, int yFu
     inout.x = apply_weight_f(inout.x, val.x, w.x, f.threshold);
     inout.y = apply_weight_f(inout.y, val.y, w.y, f.threshold);
     inout.z = apply_weight_f(inout.z, val.z, w.z, f.threshold);
+    return inout;
+}
+
+// finished value (H1, then H2 if asked for) of the pixel
+__device__ __forceinline__ pix3 finish_value(const FinishArgs& f, int x, int yFull, pix3 val, pix3 w)
+{
+    pix3 inout = finish_weighted(f, x, yFull, val, w);
     if (f.applyGamma) {
         inout.x = gamma_f(inout.x);
         inout.y = gamma_f(inout.y);
