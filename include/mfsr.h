@@ -140,30 +140,6 @@ int mfsr_accumulateSuperResFullRows(int nFrames, const uint16_t* const* dataIn, 
                                     int strideOut, int strideMask, int accumulatorsUndefined, int rowBegin, int rowEnd,
                                     mfsr_stream_t stream);
 
-/* mfsr_accumulateSuperResFullRows followed by the finish of the same HR rows: ApplyWeighting (kernel.cu:426-481) against the
- * fallback image resampled to the HR grid, GammasRGB (:393-422) if applyGamma, quantisation to maxOut -- what the LAST
- * warp+fuse launch of a burst and mfsr_finishFusedRows do one after the other.  Where an LDS tile kernel takes the frames
- * (x2 / x4 Bayer and monochrome pipelines) the finish runs in its epilogue on the sums it still holds, so the finish pass'
- * second read of both accumulators (HR x 24 B) disappears; other geometries run the two launches.  Same bits either way;
- * the accumulators hold the sums afterwards, as after mfsr_accumulateSuperResFullRows.  outImg / out16: pointers of the
- * FULL image (either may be NULL); only rows [rowBegin, rowEnd) are written. */
-typedef struct {
-    const mfsr_float3* fallback; /* may be NULL: no fallback blend */
-    int32_t fallbackPitch, fallbackWidth, fallbackHeight;
-    float threshold;
-    int32_t applyGamma;
-    float maxOut;
-    mfsr_float3* outImg;
-    int32_t outPitch;
-    uint16_t* out16;
-} mfsr_finish;
-int mfsr_accumulateSuperResFullRowsFinish(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
-                                          mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
-                                          mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
-                                          mfsr_float3 blackLevel, int dimX, int dimY, int scale, int strideOut, int strideMask,
-                                          int accumulatorsUndefined, int rowBegin, int rowEnd, const mfsr_finish* finish,
-                                          mfsr_stream_t stream);
-
 /* ---- B/E/H/I: kernel.cu --------------------------------------------------- */
 int mfsr_squaredSum(const float* inTiles, float* outValues, int maxShift, int tileSize, int tileCount,
                     mfsr_stream_t stream); /* :119 */

@@ -50,14 +50,6 @@ class PreAlign(ctypes.Structure):
                 ("tx", ctypes.c_int32), ("ty", ctypes.c_int32), ("level", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
 
 
-class Finish(ctypes.Structure):
-    """mfsr_finish (include/mfsr.h): mfsr_accumulateSuperResFullRowsFinish."""
-
-    _fields_ = [("fallback", ctypes.c_void_p), ("fallbackPitch", ctypes.c_int32), ("fallbackWidth", ctypes.c_int32),
-                ("fallbackHeight", ctypes.c_int32), ("threshold", ctypes.c_float), ("applyGamma", ctypes.c_int32),
-                ("maxOut", ctypes.c_float), ("outImg", ctypes.c_void_p), ("outPitch", ctypes.c_int32), ("out16", ctypes.c_void_p)]
-
-
 class LkFrame(ctypes.Structure):
     """mfsr_lk_frame (include/mfsr.h): one frame of mfsr_lucasKanadeSweepBatch."""
 

@@ -18,7 +18,6 @@
 //     the correctly rounded result, well inside the +-1 LSB output budget);
 //     FAST=false calls the ocml expf for tight parity tests.
 #include "accumulate_common.hpp"
-#include "finish_common.hpp"
 
 // ---- G1: accumulateImages (DeBayerKernels.cu:290-376) -------------------------
 __global__ void __launch_bounds__(256)
@@ -108,15 +107,13 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
                                        mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
                                        mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
                                        mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
-                                       int fresh, int rowBegin, int rowEnd, const FinishArgs* finishArgs,
-                                       mfsr_stream_t stream);  // accumulate_fast.hip: 2 = launched AND the rows finished
+                                       int fresh, int rowBegin, int rowEnd, mfsr_stream_t stream);  // accumulate_fast.hip
 
 int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
                                       mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
                                       mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
                                       mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
-                                      int fresh, int rowBegin, int rowEnd, const FinishArgs* finishArgs,
-                                      mfsr_stream_t stream);  // accumulate_fast.hip
+                                      int fresh, int rowBegin, int rowEnd, mfsr_stream_t stream);  // accumulate_fast.hip
 
 static int check_superres_args(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
                                const mfsr_float4* certaintyMask, const mfsr_tex2d& kernelParam, const mfsr_tex2d& shifts,
@@ -157,29 +154,20 @@ extern "C" int mfsr_accumulateImagesSuperRes(const uint16_t* dataIn, mfsr_float3
 static int accumulate_full_rows(const uint16_t* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
                                 const mfsr_float4* certaintyMask, mfsr_tex2d kernelParam, mfsr_tex2d shifts,
                                 mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int scale, int strideOut,
-                                int strideMask, int rowBegin, int rowEnd, mfsr_stream_t stream, const FinishArgs* fin = nullptr,
-                                bool* finished = nullptr)
+                                int strideMask, int rowBegin, int rowEnd, mfsr_stream_t stream)
 {
     MFSR_REQUIRE(scale >= 1 && scale <= 8);
     int rc = check_superres_args(dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, dimX, dimY,
                                  dimX * scale, strideOut, strideMask);
     if (rc) return rc;
-    if (g_accumulate_fast == 2 && scale == 2) {
-        const int r = mfsr_try_launch_accumulate2x_strip(1, &dataIn, imgOut, totalWeights, &certaintyMask, kernelParam, &shifts, whiteLevel,
-                                                         blackLevel, dimX, dimY, strideOut, strideMask, 0, rowBegin, rowEnd, fin, stream);
-        if (r >= 1) {
-            if (finished) *finished = r == 2;
-            return mfsr_launch_status("accumulateSuperResFull(strip)");
-        }
-    }
-    if (g_accumulate_fast == 2 && scale == 4) {
-        const int r = mfsr_try_launch_accumulate4x_tile(1, &dataIn, imgOut, totalWeights, &certaintyMask, kernelParam, &shifts, whiteLevel,
-                                                        blackLevel, dimX, dimY, strideOut, strideMask, 0, rowBegin, rowEnd, fin, stream);
-        if (r >= 1) {
-            if (finished) *finished = r == 2;
-            return mfsr_launch_status("accumulateSuperResFull(x4 tile)");
-        }
-    }
+    if (g_accumulate_fast == 2 && scale == 2 &&
+        mfsr_try_launch_accumulate2x_strip(1, &dataIn, imgOut, totalWeights, &certaintyMask, kernelParam, &shifts, whiteLevel,
+                                           blackLevel, dimX, dimY, strideOut, strideMask, 0, rowBegin, rowEnd, stream) == 1)
+        return mfsr_launch_status("accumulateSuperResFull(strip)");
+    if (g_accumulate_fast == 2 && scale == 4 &&
+        mfsr_try_launch_accumulate4x_tile(1, &dataIn, imgOut, totalWeights, &certaintyMask, kernelParam, &shifts, whiteLevel,
+                                          blackLevel, dimX, dimY, strideOut, strideMask, 0, rowBegin, rowEnd, stream) == 1)
+        return mfsr_launch_status("accumulateSuperResFull(x4 tile)");
     dim3 block(64, 4), grid(mfsr_cdiv((long long)dimX * scale, 64), mfsr_cdiv(rowEnd - rowBegin, 4));
     const Levels3 lv = make_levels(whiteLevel, blackLevel);
     if (g_accumulate_fast)
@@ -238,14 +226,13 @@ extern "C" int mfsr_accumulateSuperResFull2(const uint16_t* dataIn0, const uint1
 // both planes -- 0 + x == x, so the result equals the zeroed-and-accumulated one bit for bit).
 // Only HR rows [rowBegin, rowEnd) are touched (stripe-sharded bursts): rowBegin a multiple of 16, rowEnd a multiple
 // of 16 or the frame's last row + 1; every pixel of the window gets exactly what the whole-frame call gives it.
-// fin != null: the caller wants the rows finished too; *finished says whether a tile kernel's epilogue has done it
-static int accumulate_rows_impl(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut, mfsr_float3* totalWeights,
-                                const mfsr_float4* const* certaintyMask, mfsr_tex2d kernelParam, const mfsr_tex2d* shifts,
-                                mfsr_float3 whiteLevel, mfsr_float3 blackLevel, int dimX, int dimY, int scale, int strideOut,
-                                int strideMask, int accumulatorsUndefined, int rowBegin, int rowEnd, const FinishArgs* fin,
-                                bool* finished, mfsr_stream_t stream)
+extern "C" int mfsr_accumulateSuperResFullRows(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
+                                               mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
+                                               mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
+                                               mfsr_float3 blackLevel, int dimX, int dimY, int scale, int strideOut,
+                                               int strideMask, int accumulatorsUndefined, int rowBegin, int rowEnd,
+                                               mfsr_stream_t stream)
 {
-    if (finished) *finished = false;
     MFSR_REQUIRE(nFrames >= 1 && nFrames <= MFSR_MAX_FUSE_GROUP && dataIn && certaintyMask && shifts);
     MFSR_REQUIRE(scale >= 1 && scale <= 8);
     const int hrH = scale * dimY;
@@ -259,31 +246,26 @@ static int accumulate_rows_impl(int nFrames, const uint16_t* const* dataIn, mfsr
     if (g_accumulate_fast == 2 && scale == 2) {
         const int r = mfsr_try_launch_accumulate2x_strip(nFrames, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts,
                                                          whiteLevel, blackLevel, dimX, dimY, strideOut, strideMask, fresh, rowBegin,
-                                                         rowEnd, fin, stream);
-        if (r >= 1) {
-            if (finished) *finished = r == 2;
-            return mfsr_launch_status("accumulateSuperResFullN(strip)");
-        }
+                                                         rowEnd, stream);
+        if (r == 1) return mfsr_launch_status("accumulateSuperResFullN(strip)");
         if (r < 0) return MFSR_E_INVALID;
     }
     if (g_accumulate_fast == 2 && scale == 4) {
         const int r = mfsr_try_launch_accumulate4x_tile(nFrames, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts,
                                                         whiteLevel, blackLevel, dimX, dimY, strideOut, strideMask, fresh, rowBegin,
-                                                        rowEnd, fin, stream);
-        if (r >= 1) {
-            if (finished) *finished = r == 2;
-            return mfsr_launch_status("accumulateSuperResFullN(x4 tile)");
-        }
+                                                        rowEnd, stream);
+        if (r == 1) return mfsr_launch_status("accumulateSuperResFullN(x4 tile)");
         if (r < 0) return MFSR_E_INVALID;
     }
     if (nFrames > 2) {
-        // no kernel of this geometry takes the whole group: two frames, then the rest (which may finish the rows)
-        const int rc = accumulate_rows_impl(2, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, whiteLevel, blackLevel,
-                                            dimX, dimY, scale, strideOut, strideMask, accumulatorsUndefined, rowBegin, rowEnd, nullptr,
-                                            nullptr, stream);
+        // no kernel of this geometry takes the whole group: two frames, then the rest
+        const int rc = mfsr_accumulateSuperResFullRows(2, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, whiteLevel,
+                                                       blackLevel, dimX, dimY, scale, strideOut, strideMask, accumulatorsUndefined,
+                                                       rowBegin, rowEnd, stream);
         if (rc) return rc;
-        return accumulate_rows_impl(nFrames - 2, dataIn + 2, imgOut, totalWeights, certaintyMask + 2, kernelParam, shifts + 2, whiteLevel,
-                                    blackLevel, dimX, dimY, scale, strideOut, strideMask, 0, rowBegin, rowEnd, fin, finished, stream);
+        return mfsr_accumulateSuperResFullRows(nFrames - 2, dataIn + 2, imgOut, totalWeights, certaintyMask + 2, kernelParam,
+                                               shifts + 2, whiteLevel, blackLevel, dimX, dimY, scale, strideOut, strideMask, 0,
+                                               rowBegin, rowEnd, stream);
     }
     if (fresh) {
         const size_t off = (size_t)rowBegin * strideOut, bytes = (size_t)(rowEnd - rowBegin) * strideOut;
@@ -291,63 +273,11 @@ static int accumulate_rows_impl(int nFrames, const uint16_t* const* dataIn, mfsr
         MFSR_HIP_TRY(hipMemsetAsync((char*)totalWeights + off, 0, bytes, mfsr_s(stream)));
     }
     for (int n = 0; n < nFrames; n++) {
-        const bool last = n == nFrames - 1;
         const int rc = accumulate_full_rows(dataIn[n], imgOut, totalWeights, certaintyMask[n], kernelParam, shifts[n], whiteLevel,
-                                            blackLevel, dimX, dimY, scale, strideOut, strideMask, rowBegin, rowEnd, stream,
-                                            last ? fin : nullptr, last ? finished : nullptr);
+                                            blackLevel, dimX, dimY, scale, strideOut, strideMask, rowBegin, rowEnd, stream);
         if (rc) return rc;
     }
     return MFSR_OK;
-}
-
-extern "C" int mfsr_accumulateSuperResFullRows(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
-                                               mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
-                                               mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
-                                               mfsr_float3 blackLevel, int dimX, int dimY, int scale, int strideOut,
-                                               int strideMask, int accumulatorsUndefined, int rowBegin, int rowEnd,
-                                               mfsr_stream_t stream)
-{
-    return accumulate_rows_impl(nFrames, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, whiteLevel, blackLevel, dimX,
-                                dimY, scale, strideOut, strideMask, accumulatorsUndefined, rowBegin, rowEnd, nullptr, nullptr, stream);
-}
-
-// mfsr_accumulateSuperResFullRows followed by the finish of the same rows (mfsr_finishFusedRows with the whole fallback
-// image as the window: H1 + H2 + quantisation) -- what the LAST warp+fuse launch of a burst and its finish pass do.  Where
-// an LDS tile kernel takes the frames the finish happens in its epilogue, on the sums it still holds (the finish pass'
-// second read of both accumulators disappears); everywhere else the two launches follow each other.  Same bits either
-// way (one piece of code, csrc/finish_common.hpp); the accumulators hold the sums afterwards as always.
-extern "C" int mfsr_accumulateSuperResFullRowsFinish(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
-                                                     mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
-                                                     mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
-                                                     mfsr_float3 blackLevel, int dimX, int dimY, int scale, int strideOut,
-                                                     int strideMask, int accumulatorsUndefined, int rowBegin, int rowEnd,
-                                                     const mfsr_finish* finish, mfsr_stream_t stream)
-{
-    MFSR_REQUIRE(finish && (finish->outImg || finish->out16) && scale >= 1 && scale <= 8 && dimX > 0 && dimY > 0);
-    const int hrW = scale * dimX, hrH = scale * dimY;
-    MFSR_REQUIRE(finish->maxOut > 0 && finish->maxOut <= 65535.0f);
-    if (finish->outImg) MFSR_REQUIRE((long long)finish->outPitch >= 12LL * hrW && (finish->outPitch & 3) == 0);
-    if (finish->fallback)
-        MFSR_REQUIRE(finish->fallbackWidth > 0 && finish->fallbackHeight > 0 && (long long)finish->fallbackPitch >= 12LL * finish->fallbackWidth &&
-                     (finish->fallbackPitch & 3) == 0);
-    FinishArgs f;
-    f.fallback = (const pix3*)finish->fallback;
-    f.fbPitch = finish->fallbackPitch, f.fbW = finish->fallbackWidth, f.fbH = finish->fallbackHeight;
-    f.u0 = 0.0f, f.u1 = 1.0f, f.v0 = 0.0f, f.v1 = 1.0f;
-    f.threshold = finish->threshold, f.applyGamma = finish->applyGamma, f.maxOut = finish->maxOut;
-    f.width = hrW, f.fullHeight = hrH;
-    f.outImg = (pix3*)finish->outImg, f.outPitch = finish->outPitch, f.out16 = finish->out16;
-    bool finished = false;
-    const int rc = accumulate_rows_impl(nFrames, dataIn, imgOut, totalWeights, certaintyMask, kernelParam, shifts, whiteLevel, blackLevel,
-                                        dimX, dimY, scale, strideOut, strideMask, accumulatorsUndefined, rowBegin, rowEnd, &f, &finished,
-                                        stream);
-    if (rc || finished) return rc;
-    const size_t off = (size_t)rowBegin * strideOut;
-    return mfsr_finishFusedRows((const mfsr_float3*)((const char*)imgOut + off), (const mfsr_float3*)((const char*)totalWeights + off),
-                                strideOut, finish->fallback, finish->fallbackPitch, finish->fallbackWidth, finish->fallbackHeight, 0.0f, 1.0f,
-                                0.0f, 1.0f, finish->outImg ? (mfsr_float3*)((char*)finish->outImg + (size_t)rowBegin * finish->outPitch) : nullptr,
-                                finish->outPitch, finish->out16 ? finish->out16 + (size_t)rowBegin * hrW * 3 : nullptr, hrW,
-                                rowEnd - rowBegin, finish->threshold, finish->applyGamma, finish->maxOut, rowBegin, hrH, stream);
 }
 
 extern "C" int mfsr_accumulateSuperResFullN(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,

@@ -29,10 +29,8 @@
 // taps would be clamped at the frame border, strips with wild flow and strips whose kernel parameters
 // are not positive semi-definite take the straight per-pixel arithmetic (margin kernel / in-kernel path).
 #include <cstdlib>
-#include <cstring>
 
 #include "accumulate_common.hpp"
-#include "finish_common.hpp"
 #include <type_traits>
 
 namespace {
@@ -73,48 +71,6 @@ __device__ __forceinline__ float sane(float c) { return finitef(c) ? c : 0.0f; }
 __device__ __forceinline__ bool psd_ok(float kx, float ky, float kz)
 {
     return kx >= 0.0f && ky >= 0.0f && kz * kz <= kx * ky && kx < 1e30f && ky < 1e30f;
-}
-
-// Finish epilogue of the tile kernels (the burst's LAST warp+fuse launch): the strip's four pixels are normalised straight
-// from their staged sums -- H1 + H2 + quantisation through the functions k_finishFused runs (finish_common.hpp), so the
-// bits are those of the separate pass -- and the finished image leaves with the accumulators: the finish pass (HR x 24 B
-// read again) disappears.  myP / myW: the strip's 12 + 12 staged floats (value sums, weight sums); myP is overwritten with
-// the finished values (its sums have been written back by then).
-// Code size matters here: the pixel bodies before it are ~55 KB of straight-line code for a 64 KB instruction cache, so
-// the epilogue is ROLLED loops -- one copy of the weighting (three IEEE divisions, the rare fallback resample) for the four
-// pixels, one copy of powf for the twelve channel values -- with the finished values parked in LDS between the phases.
-// (Unrolled, with twelve inlined powf, it was 3 000 instructions and made the launch 0.38 ms slower.)
-__device__ __forceinline__ void finish_strip(const FinishArgs& fin, int X0, int Y, float* myP, const float* myW)
-{
-#pragma unroll 1
-    for (int k = 0; k < 4; k++) {
-        const pix3 val = {myP[3 * k], myP[3 * k + 1], myP[3 * k + 2]};
-        const pix3 w = {myW[3 * k], myW[3 * k + 1], myW[3 * k + 2]};
-        const pix3 r = finish_weighted(fin, X0 + k, Y, val, w);
-        myP[3 * k] = r.x, myP[3 * k + 1] = r.y, myP[3 * k + 2] = r.z;
-    }
-    if (fin.applyGamma) {
-#pragma unroll 1
-        for (int i = 0; i < 12; i++) myP[i] = gamma_f(myP[i]);
-    }
-    const float4 o0 = ((const float4*)myP)[0], o1 = ((const float4*)myP)[1], o2 = ((const float4*)myP)[2];
-    if (fin.outImg) {   // 48 contiguous bytes, 16-byte aligned (X0 is a multiple of 4; pitch and base checked on the host)
-        float4* d = (float4*)((char*)fin.outImg + (size_t)Y * fin.outPitch + (size_t)X0 * 12);
-        d[0] = o0;
-        d[1] = o1;
-        d[2] = o2;
-    }
-    if (fin.out16) {    // 24 contiguous bytes, 8-byte aligned
-        const float o[12] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y, o2.z, o2.w};
-        uint32_t q[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-            q[i] = (uint32_t)quantize1(o[2 * i], fin.maxOut) | ((uint32_t)quantize1(o[2 * i + 1], fin.maxOut) << 16);
-        uint2* d = (uint2*)(fin.out16 + ((size_t)Y * fin.width + X0) * 3);
-        d[0] = make_uint2(q[0], q[1]);
-        d[1] = make_uint2(q[2], q[3]);
-        d[2] = make_uint2(q[4], q[5]);
-    }
 }
 
 // one HR pixel of a safe strip.  K = position in the strip (compile time).
@@ -773,12 +729,11 @@ __global__ void __launch_bounds__(256)
 
 // FR = HR pixels per kernel-parameter / flow texel: 4 (the Bayer pipeline: fields at LR/2) or 2 (the monochrome pipeline:
 // fields at LR; 130 x 4 texels per tile, four texel columns per strip); the certainty mask is at LR/2 either way.
-// FIN: the instance with the finish epilogue (the burst's last launch); the others do not carry its code or registers
-template <int CFA, int NF, int FR = 4, bool FIN = false>
+template <int CFA, int NF, int FR = 4>
 __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR = 2: 41 / 49 KB of LDS, three workgroups per CU
     k_accumulate2xTile(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
                        Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked,
-                       int tilesX, int tilesY, int tilesPerXcd, int fresh, int tileY0, FinishArgs fin)
+                       int tilesX, int tilesY, int tilesPerXcd, int fresh, int tileY0)
 {
     // Optional XCD-aware tile order (tilesPerXcd > 0).  Workgroups are dealt round-robin to the 8 XCDs
     // (workgroup i -> XCD i & 7), each with its own L2; vertically adjacent tiles share a field-texel
@@ -794,7 +749,6 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
     static_assert(FR == 4 || FR == 2, "field resolution");
     constexpr int FC = 256 / FR + 2, FROWS = 4 / FR + 2;  // field texels a tile touches: 66 x 3 (FR = 4), 130 x 4 (FR = 2)
     constexpr int PL = (NF <= 2 || TILE_GROUP_BOTH_PLANES) ? 2 : 1;
-    static_assert(!FIN || PL == 2, "the finish epilogue needs both plane-sets staged");
     // ALIAS: the field texels live in the (not yet staged) weight-sum plane-set; see TILE_LDS_ALIAS
     constexpr bool ALIAS = TILE_LDS_ALIAS_ON && FR == 4 && NF > 2 && PL == 2;
     __shared__ __attribute__((aligned(16))) float4 sAcc[PL][4][192];
@@ -1208,11 +1162,6 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
         if (safeBits != (1u << NF) - 1u) slow_frames(Yes{}, Yes{}, 0, 1);
         store_plane(0, gP);
         store_plane(1, gW);
-        // the burst's last launch: this lane's four pixels, finished (the side-margin strips and the margin rows belong to
-        // the margin kernel, whose pixels the host finishes after it)
-        if constexpr (FIN) {
-            if (stripLive) finish_strip(fin, X0, Y, (float*)&sAcc[0][ly][0] + lx * 12, (const float*)&sAcc[1][ly][0] + lx * 12);
-        }
     } else {
         if (!valueSumsStaged) add_plane(0, accP);
         if (safeBits != (1u << NF) - 1u) slow_frames(Yes{}, No{}, 0, 0);
@@ -1347,11 +1296,11 @@ __device__ __forceinline__ void strip_pixel4(int X, int Y, int sx, int sy, float
 #define TILE4_WAVES2 3
 #endif
 // (three and four frames per launch: four workgroups per CU by the layout of TILE_LDS_ALIAS, see k_accumulate2xTile)
-template <int CFA, int NF, bool FIN = false>
+template <int CFA, int NF>
 __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : ((NF) > 2 && TILE_LDS_ALIAS_ON) ? 4 : TILE4_WAVES2)
     k_accumulate4xTile(TileFrames<NF> fr, pix3* __restrict__ imgOut, pix3* __restrict__ totalWeights, mfsr_tex2d kernelParam,
                        Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked,
-                       int tilesX, int fresh, int tileY0, FinishArgs fin)
+                       int tilesX, int fresh, int tileY0)
 {
     const int bIdYrel = (int)blockIdx.x / tilesX, bIdX = (int)blockIdx.x - bIdYrel * tilesX;
     const int bIdY = bIdYrel + tileY0;  // tileY0: first tile row of this launch's HR row window
@@ -1661,12 +1610,6 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : ((NF) > 2 && TILE_LDS_ALI
             *(float4*)(gW + off) = sAcc[1][r][h * 192 + j * 64 + lx];
         }
     }
-    if constexpr (FIN) {
-        // the burst's last launch (see k_accumulate2xTile).  The epilogue overwrites the strip's staged value sums, which
-        // the OTHER wave of the row reads in its write-back above: both must be past it
-        __syncthreads();
-        if (stripLive) finish_strip(fin, X0, Y, myP, myW);
-    }
 }
 
 constexpr int pack_cfa(int c00, int c01, int c10, int c11) { return c00 | (c01 << 2) | (c10 << 4) | (c11 << 6); }
@@ -1692,8 +1635,7 @@ bool tile_kernel_ok_fr2(mfsr_tex2d kp, mfsr_tex2d sh, int dimX, int dimY)
 
 template <int CFA, int NF, int FR = 4>
 void launch_tile(dim3 grid, dim3 block, hipStream_t st, const TileFrames<NF>& fr, pix3* imgOut, pix3* tw, mfsr_tex2d kp,
-                 Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int fresh, int tileY0,
-                 const FinishArgs& fin)
+                 Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked, int fresh, int tileY0)
 {
     const int tilesX = (int)grid.x, tilesY = (int)grid.y;
     const int tilesPerXcd = g_strip_xcd_remap ? mfsr_cdiv(tilesX * tilesY, 8) : 0;
@@ -1702,14 +1644,8 @@ void launch_tile(dim3 grid, dim3 block, hipStream_t st, const TileFrames<NF>& fr
         const char* e = getenv("MFSR_TILE_LDS_PAD");
         return e ? atoi(e) : 0;
     }();
-    if (fin.width != 0)
-        hipLaunchKernelGGL((k_accumulate2xTile<CFA, NF, FR, true>), dim3(tilesPerXcd ? 8 * tilesPerXcd : tilesX * tilesY), block, ldsPad, st,
-                           fr, imgOut, tw, kp, glv, lv, dimX, dimY, strideOut, strideMask, cfaPacked, tilesX, tilesY, tilesPerXcd, fresh,
-                           tileY0, fin);
-    else
-        hipLaunchKernelGGL((k_accumulate2xTile<CFA, NF, FR, false>), dim3(tilesPerXcd ? 8 * tilesPerXcd : tilesX * tilesY), block, ldsPad, st,
-                           fr, imgOut, tw, kp, glv, lv, dimX, dimY, strideOut, strideMask, cfaPacked, tilesX, tilesY, tilesPerXcd, fresh,
-                           tileY0, fin);
+    hipLaunchKernelGGL((k_accumulate2xTile<CFA, NF, FR>), dim3(tilesPerXcd ? 8 * tilesPerXcd : tilesX * tilesY), block, ldsPad, st, fr,
+                       imgOut, tw, kp, glv, lv, dimX, dimY, strideOut, strideMask, cfaPacked, tilesX, tilesY, tilesPerXcd, fresh, tileY0);
 }
 
 template <int CFA, int NF>
@@ -1773,20 +1709,6 @@ MarginStream* margin_stream()
     return &m;
 }
 
-// the epilogue's vectorised stores: 16-byte aligned float rows, 8-byte aligned u16 rows, an image of the accumulators' size
-bool finish_epilogue_ok(const FinishArgs& f, int hrW, int hrH)
-{
-    static const bool on = [] {
-        const char* e = getenv("MFSR_FUSE_FINISH");
-        return !(e && e[0] == '0');
-    }();
-    if (!on || f.width != hrW || f.fullHeight != hrH || (hrW & 3)) return false;
-    if (!f.outImg && !f.out16) return false;
-    if (f.outImg && ((((uintptr_t)f.outImg) & 15) || (f.outPitch & 15))) return false;
-    if (f.out16 && (((uintptr_t)f.out16) & 7)) return false;
-    return true;
-}
-
 void read_env_once()
 {
     static const bool env_read = [] {
@@ -1806,16 +1728,13 @@ void read_env_once()
 // Returns 1 if the fast kernels were launched for all `nFrames` (1 to 4) frames, 0 if the
 // configuration is not one they handle (caller falls back to the straight kernel, or splits a group of
 // three or four), -1 if a memset of the fresh-accumulator mode failed.
-// finishArgs (may be null): the caller wants the rows finished as well (H1 + H2 + quantisation).  Where an LDS tile kernel
-// takes the frames it does that in its epilogue, the frame margins are finished by a small launch after the margin
-// kernel, and the function returns 2; any other return value means the rows have NOT been finished.
 // With two to four frames the LDS tile kernel fuses all of them in one pass over the accumulators; the other
 // geometries take at most two, frame after frame.
 int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataIn, mfsr_float3* imgOut,
                                        mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
                                        mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
                                        mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
-                                       int fresh, int rowBegin, int rowEnd, const FinishArgs* finishArgs, mfsr_stream_t stream)
+                                       int fresh, int rowBegin, int rowEnd, mfsr_stream_t stream)
 {
     read_env_once();
     if (nFrames < 1 || nFrames > 4) return 0;
@@ -1824,10 +1743,6 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
     for (int i = 0; i < 4; i++)
         if (cfa[i] > MFSR_BLUE) return 0;
     const int packed2 = pack_cfa(cfa[0], cfa[1], cfa[2], cfa[3]);
-    FinishArgs fin;
-    memset((void*)&fin, 0, sizeof(fin));   // width == 0: no epilogue
-    if (finishArgs && finish_epilogue_ok(*finishArgs, 2 * dimX, 2 * dimY)) fin = *finishArgs;
-    bool finished = false;
     // layout requirements of the vectorised accumulator access
     if ((dimX & 1) || ((uintptr_t)imgOut & 15) || ((uintptr_t)totalWeights & 15) || (strideOut & 15)) return 0;
     if (dimX < 2 * STRIP_MARGIN || dimY < 2 * STRIP_MARGIN) return 0;
@@ -1895,8 +1810,7 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
             fr.f[n].shifts = shifts[n];
         }
         launch_tile<CFA, NF>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY, strideOut, strideMask, cp, tileFresh,
-                             rowBlock0, fin);
-        finished = fin.width != 0;
+                             rowBlock0);
         const int M = STRIP_MARGIN;
         const long long cnt = 2LL * (M - 1) * (hrW - 2) + (long long)(hrH - 2 * M) * 2 * (M - 1);
         hipLaunchKernelGGL((k_accumulateMarginN<NF, 2>), dim3(mfsr_cdiv(cnt, 64)), dim3(64, NF), 0, mst, fr, pI, pT, kernelParam, glv,
@@ -1916,8 +1830,7 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
                 fr.f[n].shifts = shifts[n];
             }
             launch_tile<kMono, NF, 2>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY, strideOut, strideMask, cp, tileFresh,
-                                      rowBlock0, fin);
-            finished = fin.width != 0;
+                                      rowBlock0);
             if (NF == 1) {
                 launch_margin(0);
                 return;
@@ -1933,8 +1846,7 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
         };
         if (nFrames == 1) launch_mono(std::integral_constant<int, 1>{});
         if (nFrames == 2) launch_mono(std::integral_constant<int, 2>{});
-        if (finished && mfsr_finish_margins(pI, pT, strideOut, fin, rowBegin, rowEnd, STRIP_MARGIN, st) != 0) return -1;
-        return finished ? 2 : 1;
+        return 1;
     }
 #define STRIP_CASE(a, b, c, d)                                                                                         \
     case pack_cfa(a, b, c, d):                                                                                         \
@@ -1959,17 +1871,15 @@ int mfsr_try_launch_accumulate2x_strip(int nFrames, const uint16_t* const* dataI
             fr.f[0].raw = dataIn[0];                                                                                   \
             fr.f[0].mask = (const float4*)certaintyMask[0];                                                            \
             fr.f[0].shifts = shifts[0];                                                                                \
-            if (tile_kernel_ok(kernelParam, shifts[0], dimX, dimY)) {                                                  \
+            if (tile_kernel_ok(kernelParam, shifts[0], dimX, dimY))                                                    \
                 launch_tile<pack_cfa(a, b, c, d), 1>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY,    \
-                                                     strideOut, strideMask, cp, tileFresh, rowBlock0, fin);            \
-                finished = fin.width != 0;                                                                             \
-            } else                                                                                                     \
+                                                     strideOut, strideMask, cp, tileFresh, rowBlock0);                           \
+            else                                                                                                       \
                 launch_strip_regs<pack_cfa(a, b, c, d), 1>(grid, block, st, fr, pI, pT, kernelParam, glv, lv, dimX,    \
                                                            dimY, strideOut, strideMask, cp, rowBlock0);                           \
             launch_margin(0);                                                                                          \
         }                                                                                                              \
-        if (finished && mfsr_finish_margins(pI, pT, strideOut, fin, rowBegin, rowEnd, STRIP_MARGIN, st) != 0) return -1; \
-        return finished ? 2 : 1;
+        return 1;
     switch (packed2) {
         STRIP_CASE(MFSR_RED, MFSR_GREEN, MFSR_GREEN, MFSR_BLUE)   // RGGB
         STRIP_CASE(MFSR_BLUE, MFSR_GREEN, MFSR_GREEN, MFSR_RED)   // BGGR
@@ -1988,13 +1898,10 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
                                       mfsr_float3* totalWeights, const mfsr_float4* const* certaintyMask,
                                       mfsr_tex2d kernelParam, const mfsr_tex2d* shifts, mfsr_float3 whiteLevel,
                                       mfsr_float3 blackLevel, int dimX, int dimY, int strideOut, int strideMask,
-                                      int fresh, int rowBegin, int rowEnd, const FinishArgs* finishArgs, mfsr_stream_t stream)
+                                      int fresh, int rowBegin, int rowEnd, mfsr_stream_t stream)
 {
     read_env_once();
     if (nFrames < 1 || nFrames > 4 || !g_strip_use_tile) return 0;
-    FinishArgs fin;
-    memset((void*)&fin, 0, sizeof(fin));
-    if (finishArgs && finish_epilogue_ok(*finishArgs, 4 * dimX, 4 * dimY)) fin = *finishArgs;
     int cfa[4];
     mfsr_get_cfa_pattern(cfa);
     for (int i = 0; i < 4; i++)
@@ -2050,12 +1957,8 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
             fr.f[n].mask = (const float4*)certaintyMask[n];
             fr.f[n].shifts = shifts[n];
         }
-        if (fin.width != 0)
-            hipLaunchKernelGGL((k_accumulate4xTile<CFA, NF, true>), grid, block, 0, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY, strideOut,
-                               strideMask, cp, tilesX, fresh ? 1 : 0, tileY0, fin);
-        else
-            hipLaunchKernelGGL((k_accumulate4xTile<CFA, NF, false>), grid, block, 0, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY, strideOut,
-                               strideMask, cp, tilesX, fresh ? 1 : 0, tileY0, fin);
+        hipLaunchKernelGGL((k_accumulate4xTile<CFA, NF>), grid, block, 0, st, fr, pI, pT, kernelParam, glv, lv, dimX, dimY, strideOut,
+                           strideMask, cp, tilesX, fresh ? 1 : 0, tileY0);
         if (NF == 1) {
             launch_margin(0);
             return;
@@ -2076,8 +1979,7 @@ int mfsr_try_launch_accumulate4x_tile(int nFrames, const uint16_t* const* dataIn
         if (nFrames == 2) launch_group(CfaTag{}, std::integral_constant<int, 2>{});                                    \
         if (nFrames == 3) launch_group(CfaTag{}, std::integral_constant<int, 3>{});                                    \
         if (nFrames == 4) launch_group(CfaTag{}, std::integral_constant<int, 4>{});                                    \
-        if (fin.width != 0 && mfsr_finish_margins(pI, pT, strideOut, fin, rowBegin, rowEnd, STRIP_MARGIN, st) != 0) return -1; \
-        return fin.width != 0 ? 2 : 1;                                                                                 \
+        return 1;                                                                                                      \
     }
     switch (packed2) {
         X4_CASE(MFSR_RED, MFSR_GREEN, MFSR_GREEN, MFSR_BLUE)   // RGGB

@@ -8,7 +8,6 @@
 #include <cstring>
 
 #include "common.hpp"
-#include "finish_common.hpp"
 
 extern "C" const char* mfsr_error_string(int code)
 {
@@ -374,6 +373,20 @@ extern "C" int mfsr_float3ToFloat4(const mfsr_float3* in, int inPitch, mfsr_floa
     return mfsr_launch_status("float3ToFloat4");
 }
 
+// bilinear fetch of a float3 image (clamp) -- shared with finishFused
+__device__ __forceinline__ pix3 sample_pix3(const pix3* __restrict__ in, int inPitch, int inW, int inH, float u, float v)
+{
+    const TexCoord c = tex_coord<ADDR_CLAMP>(inW, inH, u, v);
+    const pix3* r0 = row_ptr(in, inPitch, c.j0);
+    const pix3* r1 = row_ptr(in, inPitch, c.j1);
+    const pix3 t00 = r0[c.i0], t10 = r0[c.i1], t01 = r1[c.i0], t11 = r1[c.i1];
+    pix3 o;
+    o.x = lerp4(t00.x, t10.x, t01.x, t11.x, c.a, c.b);
+    o.y = lerp4(t00.y, t10.y, t01.y, t11.y, c.a, c.b);
+    o.z = lerp4(t00.z, t10.z, t01.z, t11.z, c.a, c.b);
+    return o;
+}
+
 __global__ void __launch_bounds__(256) k_resampleFloat3(const pix3* __restrict__ in, int inPitch, int inW, int inH,
                                                        pix3* __restrict__ out, int outPitch, int outW, int outH, float u0,
                                                        float u1, float v0, float v1)
@@ -396,6 +409,13 @@ extern "C" int mfsr_resampleFloat3(const mfsr_float3* in, int inPitch, int inW, 
     hipLaunchKernelGGL(k_resampleFloat3, grid, block, 0, mfsr_s(stream), (const pix3*)in, inPitch, inW, inH, (pix3*)out,
                        outPitch, outW, outH, u0, u1, v0, v1);
     return mfsr_launch_status("resampleFloat3");
+}
+
+__device__ __forceinline__ int quantize1(float f, float maxOut)
+{
+    if (isnan(f)) f = 0;
+    f = fmaxf(fminf(f, 1.0f), 0.0f);
+    return (int)(f * maxOut + 0.5f);
 }
 
 __global__ void __launch_bounds__(256) k_quantize(const pix3* __restrict__ in, int inPitch, uint16_t* __restrict__ out16,
@@ -537,52 +557,64 @@ extern "C" int mfsr_structureTensorFused(const float* img, int imgPitch, mfsr_fl
     return mfsr_launch_status("structureTensorFused");
 }
 
-// ---- H1 (+fallback resample) + H2 + quantise in one launch (the per-pixel arithmetic: finish_common.hpp) --------------
-// sideM > 0: the launch covers only the 2 * sideM outermost columns of every row (the side margins of the frame: what is
-// left of a row window after the warp+fuse tile kernels' own finish epilogue, accumulate_fast.hip); `width` stays the
-// image's width
-__global__ void __launch_bounds__(256)
-    k_finishFused(const pix3* __restrict__ finalImg, const pix3* __restrict__ weight, int imgPitch, FinishArgs f, int height,
-                  int rowOffset, int sideM)
+// ---- H1 (+fallback resample) + H2 + quantise in one launch ---------------------------
+__device__ __forceinline__ float apply_weight_f(float inout, float val, float w, float threshold)
 {
-    const int xi = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    const int width = f.width;
-    if (y >= height || xi >= (sideM > 0 ? 2 * sideM : width)) return;
-    const int x = sideM > 0 ? (xi < sideM ? xi : width - 2 * sideM + xi) : xi;
-    const pix3 val = row_ptr(finalImg, imgPitch, y)[x];
-    const pix3 w = row_ptr(weight, imgPitch, y)[x];
-    // row y of this launch is row y + rowOffset of a fullHeight-row image: the same float expression as the whole-image
-    // launch evaluates for that row, so a stripe-wise finish is bit-identical to the whole one
-    const pix3 inout = finish_value(f, x, y + rowOffset, val, w);
-    if (f.outImg) row_ptr(f.outImg, f.outPitch, y)[x] = inout;
-    if (f.out16) {
-        const size_t o = ((size_t)y * width + x) * 3;
-        f.out16[o] = (uint16_t)quantize1(inout.x, f.maxOut);
-        f.out16[o + 1] = (uint16_t)quantize1(inout.y, f.maxOut);
-        f.out16[o + 2] = (uint16_t)quantize1(inout.z, f.maxOut);
+    // kernel.cu:447-456
+    if (w < threshold) {
+        val += inout;
+        w += 1;
     }
+    inout = 0;
+    if (w != 0) inout = val / w;
+    return inout;
 }
 
-int mfsr_finish_margins(const pix3* imgOut, const pix3* totalWeights, int pitch, const FinishArgs& fin, int rowBegin, int rowEnd, int M,
-                        hipStream_t st)
+__device__ __forceinline__ float gamma_f(float v)
 {
-    const int hrH = fin.fullHeight, hrW = fin.width;
-    auto rows = [&](int r0, int r1, int sideM) {   // rows [r0, r1) of the full image
-        if (r1 <= r0) return;
-        FinishArgs f = fin;   // k_finishFused indexes its outputs by the launch's own rows: hand it row r0's pointers
-        f.outImg = fin.outImg ? (pix3*)((char*)fin.outImg + (size_t)r0 * fin.outPitch) : nullptr;
-        f.out16 = fin.out16 ? fin.out16 + (size_t)r0 * hrW * 3 : nullptr;
-        dim3 block(64, 4), grid(mfsr_cdiv(sideM > 0 ? 2 * sideM : hrW, 64), mfsr_cdiv(r1 - r0, 4));
-        hipLaunchKernelGGL(k_finishFused, grid, block, 0, st, (const pix3*)((const char*)imgOut + (size_t)r0 * pitch),
-                           (const pix3*)((const char*)totalWeights + (size_t)r0 * pitch), pitch, f, r1 - r0, r0, sideM);
-    };
-    auto mx = [](int a, int b) { return a > b ? a : b; };
-    auto mn = [](int a, int b) { return a < b ? a : b; };
-    rows(mx(rowBegin, 0), mn(rowEnd, M), 0);
-    rows(mx(rowBegin, hrH - M), mn(rowEnd, hrH), 0);
-    if (2 * M < hrW) rows(mx(rowBegin, M), mn(rowEnd, hrH - M), M);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    // kernel.cu:380-390, :407-420
+    if (isnan(v)) v = 0;
+    v = fmaxf(fminf(v, 1.0f), 0.0f);
+    if (v <= 0.0031308f) return 12.92f * v;
+    return (1.0f + 0.055f) * powf(v, 1.0f / 2.4f) - 0.055f;
+}
+
+__global__ void __launch_bounds__(256)
+    k_finishFused(const pix3* __restrict__ finalImg, const pix3* __restrict__ weight, int imgPitch,
+                  const pix3* __restrict__ fallback, int fbPitch, int fbW, int fbH, float u0, float u1, float v0, float v1,
+                  pix3* __restrict__ outImg, int outPitch, uint16_t* __restrict__ out16, int width, int height,
+                  float threshold, int applyGamma, float maxOut, int rowOffset, int fullHeight)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= width || y >= height) return;
+    const pix3 val = row_ptr(finalImg, imgPitch, y)[x];
+    const pix3 w = row_ptr(weight, imgPitch, y)[x];
+    pix3 inout = {0.0f, 0.0f, 0.0f};
+    // ApplyWeighting reads the fallback only where a weight is under the threshold (kernel.cu:444-462): the resample (12
+    // loads, two divisions, the bilinear mix: 40 % of this kernel's instructions) is skipped by the waves that need none
+    if (fallback && (w.x < threshold || w.y < threshold || w.z < threshold)) {
+        const float u = u0 + (u1 - u0) * (((float)x + 0.5f) / (float)width);
+        // row y of this launch is row y + rowOffset of a fullHeight-row image: the same float expression as the whole-image
+        // launch evaluates for that row, so a stripe-wise finish is bit-identical to the whole one
+        const float v = v0 + (v1 - v0) * (((float)(y + rowOffset) + 0.5f) / (float)fullHeight);
+        inout = sample_pix3(fallback, fbPitch, fbW, fbH, u, v);
+    }
+    inout.x = apply_weight_f(inout.x, val.x, w.x, threshold);
+    inout.y = apply_weight_f(inout.y, val.y, w.y, threshold);
+    inout.z = apply_weight_f(inout.z, val.z, w.z, threshold);
+    if (applyGamma) {
+        inout.x = gamma_f(inout.x);
+        inout.y = gamma_f(inout.y);
+        inout.z = gamma_f(inout.z);
+    }
+    if (outImg) row_ptr(outImg, outPitch, y)[x] = inout;
+    if (out16) {
+        const size_t o = ((size_t)y * width + x) * 3;
+        out16[o] = (uint16_t)quantize1(inout.x, maxOut);
+        out16[o + 1] = (uint16_t)quantize1(inout.y, maxOut);
+        out16[o + 2] = (uint16_t)quantize1(inout.z, maxOut);
+    }
 }
 
 // rows [rowOffset, rowOffset + height) of a fullHeight-row image whose fallback window is (u0..u1, v0..v1); the image
@@ -599,16 +631,10 @@ extern "C" int mfsr_finishFusedRows(const mfsr_float3* finalImg, const mfsr_floa
     if (fallback) MFSR_REQUIRE(fbW > 0 && fbH > 0 && (long long)fbPitch >= 12LL * fbW && (fbPitch & 3) == 0);
     MFSR_REQUIRE(maxOut > 0 && maxOut <= 65535.0f);
     MFSR_REQUIRE(rowOffset >= 0 && fullHeight >= rowOffset + height);
-    FinishArgs f;
-    f.fallback = (const pix3*)fallback;
-    f.fbPitch = fbPitch, f.fbW = fbW, f.fbH = fbH;
-    f.u0 = u0, f.u1 = u1, f.v0 = v0, f.v1 = v1;
-    f.threshold = threshold, f.applyGamma = applyGamma, f.maxOut = maxOut;
-    f.width = width, f.fullHeight = fullHeight;
-    f.outImg = (pix3*)outImg, f.outPitch = outPitch, f.out16 = out16;   // (pointers of the stripe's first row, like the inputs)
     dim3 block(64, 4), grid(mfsr_cdiv(width, 64), mfsr_cdiv(height, 4));
-    hipLaunchKernelGGL(k_finishFused, grid, block, 0, mfsr_s(stream), (const pix3*)finalImg, (const pix3*)weight, imgPitch, f, height,
-                       rowOffset, 0);
+    hipLaunchKernelGGL(k_finishFused, grid, block, 0, mfsr_s(stream), (const pix3*)finalImg, (const pix3*)weight, imgPitch,
+                       (const pix3*)fallback, fbPitch, fbW, fbH, u0, u1, v0, v1, (pix3*)outImg, outPitch, out16, width,
+                       height, threshold, applyGamma, maxOut, rowOffset, fullHeight);
     return mfsr_launch_status("finishFused");
 }
 

@@ -1304,17 +1304,6 @@ static int align_deferred(mfsr_burst* b, mfsr_stream_t stream)
     return MFSR_OK;
 }
 
-// The burst's last group waits for mfsr_burst_finish, whose launch also normalises the pixels (finish_fused) -- unless
-// MFSR_FUSE_FINISH=0 (A/B) or the unfused chain is selected.
-static bool fuse_finish_on(const mfsr_burst* b)
-{
-    static const bool on = [] {
-        const char* e = getenv("MFSR_FUSE_FINISH");
-        return !(e && e[0] == '0');
-    }();
-    return on && b->cfg.fused;
-}
-
 // hostBurst: the frame belongs to a host-frame burst (mfsr_burst_add_frame_host), whose last groups wait for
 // mfsr_burst_finish_host; a frame added through mfsr_burst_add_frame never leaves a complete group waiting
 static int add_frame_impl(mfsr_burst* b, const uint16_t* raw, int isReference, mfsr_float3* imgOut, mfsr_float3* totalWeights,
@@ -1358,10 +1347,6 @@ static int add_frame_impl(mfsr_burst* b, const uint16_t* raw, int isReference, m
     // finished bands of the image leave for the host while the later ones are still being fused
     // (only the group the burst's LAST frame completes: frames beyond cfg.frames are fused as they come)
     if (b->holdLastGroup && b->framesSinceRef == c.frames) return MFSR_OK;
-    // resident bursts: the same group waits for mfsr_burst_finish, whose warp+fuse launch then also normalises the pixels it
-    // has just accumulated (finish_fused: no finish pass over the accumulators); a flush, another frame or other
-    // accumulators fuse it the ordinary way
-    if (!b->holdLastGroup && fuse_finish_on(b) && b->framesSinceRef == c.frames) return MFSR_OK;
     // ... and so does the group before it (MFSR_HOST_HOLD=2, the default): the first band of the image is then complete after
     // 1/8 of two groups' fuse instead of after a whole group's, and the download -- the tail of the burst -- starts that much
     // earlier; the earlier groups are fused as they arrive, under the uploads
@@ -1576,94 +1561,11 @@ extern "C" int mfsr_burst_flush(mfsr_burst* b, mfsr_stream_t stream)
     return flush_pending(b, stream);
 }
 
-// The burst's last group, still waiting (add_frame_impl), fused by a launch that also finishes the image:
-// mfsr_accumulateSuperResFullRowsFinish -- where the LDS tile kernels serve the geometry the finish is their epilogue, on the
-// sums they still hold, and the finish pass (HR x 24 B read again, 0.17 ms at 4K x2) disappears; elsewhere it is the two
-// launches as before.  Same bits either way; the accumulators hold the sums afterwards as always.
-static int finish_fused(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights, mfsr_float3* outImg,
-                        uint16_t* out16, mfsr_stream_t callerStream)
-{
-    const mfsr_config& c = b->cfg;
-    Layout& L = b->L;
-    TRY(align_deferred(b, callerStream));
-    const mfsr_burst::Pending p = b->pend;
-    b->pend.n = 0;
-    const int n = p.n;
-    mfsr_stream_t stream = callerStream;
-    if (b->fuseStream) {
-        stream = (mfsr_stream_t)b->fuseStream;
-        for (int i = 0; i < n; i++) MFSR_HIP_TRY(hipStreamWaitEvent(b->fuseStream, b->evAligned[p.slot[i]], 0));
-    }
-    TRY(wait_ref_products(b, stream));  // the finish reads the fallback image
-    const int freshNow = b->fresh.has && b->fresh.imgOut == imgOut && b->fresh.totalWeights == totalWeights;
-    if (b->fresh.has && !freshNow) {
-        const size_t bytes = (size_t)12 * L.hrW * L.hrH;
-        MFSR_HIP_TRY(hipMemsetAsync(b->fresh.imgOut, 0, bytes, mfsr_s(stream)));
-        MFSR_HIP_TRY(hipMemsetAsync(b->fresh.totalWeights, 0, bytes, mfsr_s(stream)));
-    }
-    b->fresh.has = false;
-    const mfsr_float3 white = {c.white[0], c.white[1], c.white[2]};
-    const mfsr_float3 black = {c.black[0], c.black[1], c.black[2]};
-    TRY(mfsr_set_cfa_pattern(c.cfa));
-    const mfsr_float4* masks[MFSR_MAX_FUSE_GROUP];
-    mfsr_tex2d flows[MFSR_MAX_FUSE_GROUP];
-    for (int k = 0; k < n; k++) {
-        masks[k] = (const mfsr_float4*)p.mask[k]->ptr;
-        flows[k] = as_tex(*p.flow[k]);
-    }
-    const int pitch = 12 * L.hrW;
-    mfsr_finish fin;
-    memset(&fin, 0, sizeof(fin));
-    fin.fallback = (const mfsr_float3*)L.fallback.ptr;
-    fin.fallbackPitch = L.fallback.pitch;
-    fin.fallbackWidth = L.W;
-    fin.fallbackHeight = L.H;
-    fin.threshold = c.weightThreshold;
-    fin.applyGamma = c.applyGamma;
-    fin.maxOut = 65535.0f;
-    fin.outImg = outImg;
-    fin.outPitch = pitch;
-    fin.out16 = out16;
-    const bool timed = b->timing && b->nEvents < kMaxTimedLaunches;
-    if (timed) {
-        const int i = b->nEvents;
-        if (!b->evStart[i]) MFSR_HIP_TRY(hipEventCreate(&b->evStart[i]));
-        if (!b->evStop[i]) MFSR_HIP_TRY(hipEventCreate(&b->evStop[i]));
-        MFSR_HIP_TRY(hipEventRecord(b->evStart[i], mfsr_s(stream)));
-    }
-    TRY(mfsr_accumulateSuperResFullRowsFinish(n, p.raw, const_cast<mfsr_float3*>(imgOut), const_cast<mfsr_float3*>(totalWeights), masks,
-                                              as_tex(L.kparam4), flows, white, black, L.W, L.H, c.scale, pitch, p.mask[0]->pitch, freshNow,
-                                              0, L.hrH, &fin, stream));
-    if (timed) {
-        MFSR_HIP_TRY(hipEventRecord(b->evStop[b->nEvents], mfsr_s(stream)));
-        b->nEvents++;
-        b->nFramesTimed += n;
-    }
-    if (b->copyStream) {
-        for (int j = 0; j < n; j++) {
-            const int us = upload_slot_of(b, p.raw[j]);
-            if (us >= 0) {
-                MFSR_HIP_TRY(hipEventRecord(b->evFree[us], mfsr_s(stream)));
-                b->freeRecorded[us] = true;
-            }
-        }
-    }
-    if (b->fuseStream) {
-        for (int i = 0; i < n; i++) {
-            MFSR_HIP_TRY(hipEventRecord(b->evFused[p.slot[i]], b->fuseStream));
-            b->fusedOutstanding[p.slot[i]] = true;
-        }
-    }
-    return join_fuse(b, callerStream);
-}
-
 extern "C" int mfsr_burst_finish(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_float3* totalWeights,
                                  mfsr_float3* outImg, uint16_t* out16, mfsr_stream_t stream)
 {
     MFSR_REQUIRE(b && imgOut && totalWeights && (outImg || out16));
     MFSR_REQUIRE(b->haveRef);
-    if (fuse_finish_on(b) && !b->heldHas && b->pend.n > 0 && b->pend.imgOut == imgOut && b->pend.totalWeights == totalWeights)
-        return finish_fused(b, imgOut, totalWeights, outImg, out16, stream);
     TRY(flush_pending(b, stream));
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;

@@ -375,85 +375,6 @@ def test_accumulate_saturated_certainty_path(orc, hip, n, field, s, pat):
     assert not np.array_equal(aw[:, ~far], bw[:, ~far])
 
 
-@pytest.mark.parametrize("n,field,s,pat,W,H,rows,fresh,gamma", [
-    (4, "quarter", 2, "RGGB", 840, 88, None, 0, 0), (4, "quarter", 2, "GBRG", 840, 88, (32, 144), 0, 1), (3, "quarter", 2, "BGGR", 520, 72, None, 1, 0),
-    (2, "quarter", 2, "GRBG", 840, 88, (0, 48), 1, 1), (1, "quarter", 2, "RGGB", 520, 72, None, 0, 0), (2, "half", 2, "MONO", 840, 88, None, 0, 1),
-    (4, "quarter", 4, "RGGB", 520, 72, None, 0, 0), (2, "quarter", 4, "GBRG", 520, 72, (64, 288), 1, 1),
-    (3, "odd", 2, "RGGB", 264, 72, None, 0, 0),            # a field size no tile kernel serves: the two launches behind the same call
-    (2, "quarter", 3, "RGGB", 264, 72, None, 0, 1),        # x3: the straight kernel + the finish pass
-])
-def test_accumulate_with_finish_epilogue_is_bit_identical(hip, n, field, s, pat, W, H, rows, fresh, gamma):
-    """mfsr_accumulateSuperResFullRowsFinish (the burst's last warp+fuse launch normalises the pixels it has just accumulated:
-    the epilogue of the LDS tile kernels + a small launch for the frame margins) against mfsr_accumulateSuperResFullRows
-    followed by mfsr_finishFusedRows on the same rows: the float image, the u16 image AND the accumulators must be the same
-    bits, for whole frames and row windows, first-of-burst (fresh) launches, gamma on and off, weights under the threshold
-    (fallback blend), one to four frames, x2 / x4 / x3, Bayer and monochrome, and geometries the tile kernels do not serve."""
-    import torch
-    from multi_frame_super_resolution_amd import capi
-    dev = hip.dev
-    cfa = [1, 1, 1, 1] if pat == "MONO" else PATTERNS[pat]
-    hip.set_cfa(cfa)
-    white, black = F3([3839, 3700, 3900]), F3([256, 260, 250])
-    fh, fw = {"quarter": (H // 2, W // 2), "half": (H, W), "odd": (H // 2 - 3, W // 2 - 5)}[field]
-    kp = _kernel_field(370, fh, fw, 4)
-    yy, xx = np.mgrid[0:fh, 0:fw].astype(np.float32)
-    mh, mw = (H + 1) // 2, (W + 1) // 2
-    r = rng(371)
-    hrW, hrH = W * s, H * s
-    frames = []
-    for k in range(n):
-        raw, _, _, _ = _accum_inputs(372 + k, W, H, hrW, hrH)
-        mask = r.random((mh, mw, 4), dtype=np.float32)
-        mask[:, : mw // 4] = 1.0                                   # saturated-certainty body in part of the frame
-        mask[mh // 3: mh // 2, mw // 2: mw // 2 + 30] = 0.0        # nothing fused there: weights under the threshold -> fallback
-        sh = np.stack([1.3 - 0.9 * k + 0.01 * xx, -2.2 + 1.1 * k + 0.02 * yy], -1).astype(np.float32)
-        frames.append((raw, np.ascontiguousarray(mask), np.ascontiguousarray(sh)))
-    _, acc_i, acc_w, _ = _accum_inputs(399, W, H, hrW, hrH)
-    acc_i *= 0.05
-    acc_w *= 0.002                                                  # small weights: the threshold (1e-3) matters on many pixels
-    fallback = rng(398).random((H, W, 3), dtype=np.float32)
-    r0, r1 = rows if rows else (0, hrH)
-    d_raw = [torch.from_numpy(f[0].view(np.int16)).to(dev) for f in frames]
-    d_mask = [torch.from_numpy(f[1]).to(dev) for f in frames]
-    d_sh = [torch.from_numpy(f[2]).to(dev) for f in frames]
-    d_kp = torch.from_numpy(kp).to(dev)
-    d_fb = torch.from_numpy(fallback).to(dev)
-    P = ctypes.c_void_p * n
-    T = capi.Tex2D * n
-    shs = T(*[capi.Tex2D(t.data_ptr(), fw * 8, fw, fh) for t in d_sh])
-    kpt = capi.Tex2D(d_kp.data_ptr(), fw * 16, fw, fh)
-    raws, masks = P(*[t.data_ptr() for t in d_raw]), P(*[t.data_ptr() for t in d_mask])
-    pitch = hrW * 12
-
-    def run(fusedCall):
-        d_i, d_w = torch.from_numpy(acc_i).to(dev), torch.from_numpy(acc_w).to(dev)
-        out = torch.full((hrH, hrW, 3), -7.0, dtype=torch.float32, device=dev)
-        out16 = torch.full((hrH, hrW, 3), 12345, dtype=torch.int16, device=dev)
-        if fusedCall:
-            fin = capi.Finish(d_fb.data_ptr(), W * 12, W, H, 1e-3, gamma, 65535.0, out.data_ptr(), pitch, out16.data_ptr())
-            hip.L.accumulateSuperResFullRowsFinish(n, raws, d_i.data_ptr(), d_w.data_ptr(), masks, kpt, shs, capi.f3(white.v), capi.f3(black.v),
-                                                   W, H, s, pitch, mw * 16, fresh, r0, r1, ctypes.byref(fin), None)
-        else:
-            hip.L.accumulateSuperResFullRows(n, raws, d_i.data_ptr(), d_w.data_ptr(), masks, kpt, shs, capi.f3(white.v), capi.f3(black.v),
-                                             W, H, s, pitch, mw * 16, fresh, r0, r1, None)
-            off = r0 * pitch
-            hip.L.finishFusedRows(d_i.data_ptr() + off, d_w.data_ptr() + off, pitch, d_fb.data_ptr(), W * 12, W, H, 0.0, 1.0, 0.0, 1.0,
-                                  out.data_ptr() + off, pitch, out16.data_ptr() + r0 * hrW * 6, hrW, r1 - r0, 1e-3, gamma, 65535.0, r0, hrH, None)
-        torch.cuda.synchronize()
-        return d_i.cpu().numpy(), d_w.cpu().numpy(), out.cpu().numpy(), out16.cpu().numpy()
-
-    a = run(False)
-    b = run(True)
-    for x, y, what in zip(a, b, ("imgOut", "totalWeights", "finished float image", "finished u16 image")):
-        assert np.array_equal(x, y, equal_nan=True), what
-    # the rows outside the window are untouched, the window is written everywhere
-    assert (a[2][:r0] == -7.0).all() and (a[2][r1:] == -7.0).all() and not (b[2][r0:r1] == -7.0).any()
-    assert (b[3][:r0] == 12345).all() and (b[3][r1:] == 12345).all()
-    # and the test is not vacuous: the fallback was blended in somewhere, fused values elsewhere
-    thr = (b[1][r0:r1] < 1e-3)
-    assert 0.001 < thr.mean() < 0.9
-
-
 @pytest.mark.parametrize("s,base", [(2, (70.3, -40.2)), (4, (70.3, -40.2)), (2, (-150.6, 33.0)), (4, (12.2, 90.7))])
 def test_accumulate_large_global_shift(orc, hip, s, base):
     """Frames displaced by tens to hundreds of pixels as a whole (a hand-held burst before any stabilisation): the group
