@@ -71,6 +71,23 @@ for wl in wls:
 
     fetch, write, valu = per_launch("FETCH_SIZE"), per_launch("WRITE_SIZE"), per_launch("SQ_INSTS_VALU")
     hbm = 2 * fetch * 1024 + write * 1024
+    # read requests by size (pass 4): exact bytes at the L2's memory side (Infinity-Cache hits included)
+    r32, r64, r128, rall = (per_launch("TCC_EA0_RDREQ_32B_sum"), per_launch("TCC_EA0_RDREQ_64B_sum"), per_launch("TCC_EA0_RDREQ_128B_sum"),
+                            per_launch("TCC_EA0_RDREQ_sum"))
+    w64, wall = per_launch("TCC_EA0_WRREQ_64B_sum"), per_launch("TCC_EA0_WRREQ_sum")
+    read_exact = 32 * r32 + 64 * r64 + 128 * r128 if rall else None
+    write_exact = 64 * w64 + 32 * (wall - w64) if wall else None
+    # the tile kernel's dispatches in two classes: the first launch of a burst reads no accumulators (fresh), the others do
+    first_later = None
+    try:
+        vals = sorted(per[k].get("TCC_EA0_RDREQ_128B_sum") or per[k].get("FETCH_SIZE") or [])
+        if len(vals) >= 4:
+            lo = [v for v in vals if v < 0.75 * vals[-1]]
+            hi = [v for v in vals if v >= 0.75 * vals[-1]]
+            if lo and hi:
+                first_later = (sum(lo) / len(lo), len(lo), sum(hi) / len(hi), len(hi))
+    except Exception:
+        first_later = None
     mk = re.search(r"k_\w+", k)
     kname = mk.group(0) if mk else k
     # frames per launch of the profiled run (bench.py's own line in the pass log): bench.py applies the entry only to runs
@@ -86,7 +103,20 @@ for wl in wls:
                "kernel_source_sha16": fuse_source_sha16(),
                "source": f"rocprofv3 --pmc passes of tools/gpu_pmc_workloads.sh ({kname}: {n_main} dispatches + "
                          f"{n_margin} margin dispatches per burst)"}
+    if read_exact:
+        res[wl]["hbm_bytes_per_launch_2xfetch"] = res[wl]["hbm_bytes_per_launch"]
+        res[wl]["read_bytes_by_request_size"] = int(read_exact)
+        res[wl]["write_bytes_by_request_size"] = int(write_exact) if write_exact else int(write * 1024)
+        res[wl]["hbm_bytes_per_launch"] = int(read_exact + (write_exact if write_exact else write * 1024))
+        res[wl]["traffic_note"] = ("reads = 32 x RDREQ_32B + 64 x RDREQ_64B + 128 x RDREQ_128B, writes = 64 x WRREQ_64B + 32 x the rest, at the L2's "
+                                   "memory side (Infinity-Cache hits included); hbm_bytes_per_launch_2xfetch = 2 x FETCH_SIZE + WRITE_SIZE")
     lines.append(f"{wl}: kernel {k[:90]}")
+    if read_exact:
+        lines.append(f"  read requests per launch: 32 B {r32:.4g}, 64 B {r64:.4g}, 128 B {r128:.4g} (all {rall:.4g}) -> {read_exact / 1e9:.3f} GB read; "
+                     f"write requests {wall:.4g} ({w64:.4g} of 64 B) -> {(write_exact or 0) / 1e9:.3f} GB written; 2 x FETCH_SIZE would say {2 * fetch * 1024 / 1e9:.3f} GB read")
+    if first_later:
+        lines.append(f"  tile kernel, 128-B read requests (or FETCH_SIZE KB) per dispatch: first launch of a burst {first_later[0]:.4g} (n={first_later[1]}), "
+                     f"later launches {first_later[2]:.4g} (n={first_later[3]})")
     lines.append(f"  dispatches per burst: {n_main} (+{n_margin} margin); per launch: FETCH_SIZE {fetch:.0f} KB, WRITE_SIZE {write:.0f} KB, "
                  f"HBM bytes (2*F+W) {hbm / 1e9:.3f} GB, SQ_INSTS_VALU {valu:.4g}, waves {per_launch('SQ_WAVES'):.0f}")
 mix = static_mix([MIX_KERNEL[w] for w in res if w in MIX_KERNEL])
