@@ -735,12 +735,16 @@ __global__ void __launch_bounds__(256, (FR != 4 ? 3 : TILE_WAVES_NF(NF)))  // FR
                        Levels3 glv, StripLevels lv, int dimX, int dimY, int strideOut, int strideMask, int cfaPacked,
                        int tilesX, int tilesY, int tilesPerXcd, int fresh, int tileY0)
 {
-    // Optional XCD-aware tile order (tilesPerXcd > 0).  Workgroups are dealt round-robin to the 8 XCDs
-    // (workgroup i -> XCD i & 7), each with its own L2; vertically adjacent tiles share a field-texel
-    // row, a certainty row and two raw rows but sit on different XCDs in launch order.  With the
-    // remap XCD k walks its own contiguous band of tiles in row-major order so those rows are L2
-    // hits.  Measured on MI355X: no gain (0.402 vs 0.398 ms) -- the shared rows are 5 % of the
-    // bytes and are served by the Infinity Cache either way -- so launch order is the default.
+    // XCD-aware tile order (tilesPerXcd > 0, the default since round 4).  Workgroups are dealt round-robin to the 8 XCDs
+    // (workgroup i -> XCD i & 7), each with its own L2.  A 256 x 4 tile stages 66 x 3 field texels (kernel parameters, the
+    // flows and certainties of its frames: 112 B per texel with four frames) of which it owns 64 x 1, and its raw rows
+    // overlap those of the tiles above and below: in launch order vertically adjacent tiles sit on DIFFERENT XCDs, so every
+    // one of those re-reads misses its L2 and goes to the fabric (served by the Infinity Cache, counted by the L2's
+    // memory-side counters): 1.16 GB read per launch beyond the accumulators against 0.30 GB of inputs (PMC, request-size
+    // counters, profiles/r04_pmc_fuse_xcd.txt).  With the remap XCD k walks its own contiguous band of tiles in row-major
+    // order, the neighbours are L2 hits, and the launch reads 0.305 GB + the accumulators: exactly its inputs.  The launch
+    // time does not move (0.86 ms either way: the kernel is not bound by bytes) -- what it buys is 0.87 GB less fabric
+    // traffic per launch for the kernels running beside it, and a traffic figure that is the algorithmic one.
     const int pid = (int)blockIdx.x;
     const int tile = tilesPerXcd > 0 ? (pid & 7) * tilesPerXcd + (pid >> 3) : pid;  // tilesPerXcd == 0: launch order (A/B)
     if (tile >= tilesX * tilesY) return;  // whole workgroup (uniform), before any barrier
@@ -1614,7 +1618,7 @@ __global__ void __launch_bounds__(256, (NF) == 1 ? 4 : ((NF) > 2 && TILE_LDS_ALI
 
 constexpr int pack_cfa(int c00, int c01, int c10, int c11) { return c00 | (c01 << 2) | (c10 << 4) | (c11 << 6); }
 
-int g_strip_xcd_remap = 0;  // MFSR_XCD_REMAP=1: XCD-aware tile order (measured: no gain)
+int g_strip_xcd_remap = 1;  // MFSR_XCD_REMAP=0: launch order (A/B); see k_accumulate2xTile
 int g_strip_use_tile = 1;  // MFSR_STRIP_TILE: 0 register-only strip kernel, 1 LDS tile kernel (fields at HR/4)
 
 // true when the LDS tile kernel serves this geometry (fields at HR/4, whole tiles)
