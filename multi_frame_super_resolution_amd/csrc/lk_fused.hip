@@ -557,12 +557,26 @@ __device__ __forceinline__ float lk_warp_finish(const float* __restrict__ movedI
 template <int HT>
 __global__ void __launch_bounds__(64)
     k_lkSweep(LkSweepBatch batch, const float* __restrict__ refImg, int pitchShift, int pitchImg, int pitchSD, int width, int height,
-              float minDet, float outScale, int bandRows)
+              float minDet, float outScale, int bandRows, int strips, int bands, int perXcd, int nFramesLaunch)
 {
     constexpr int h = HT, HALO = HT + 2, WIN = 2 * HT + 1, VW = 64 - 2 * HALO;
-    const LkSweepFrame F = batch.f[blockIdx.z];
+    // XCD-aware order (perXcd > 0): workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  A band re-reads
+    // 2 (h + 2) rows of its vertical neighbours and a strip 2 (h + 2) columns of its horizontal ones; in launch order the
+    // band below sits `strips` workgroups later, on another XCD.  Here XCD k walks its own contiguous run of (frame, band,
+    // strip) tiles, so those halos are hits in its L2 instead of trips to the fabric.
+    int sIdx, bIdx, fIdx;
+    if (perXcd > 0) {
+        const int t = ((int)blockIdx.x & 7) * perXcd + ((int)blockIdx.x >> 3);
+        if (t >= strips * bands * nFramesLaunch) return;
+        sIdx = t % strips;
+        bIdx = (t / strips) % bands;
+        fIdx = t / (strips * bands);
+    } else {
+        sIdx = blockIdx.x, bIdx = blockIdx.y, fIdx = blockIdx.z;
+    }
+    const LkSweepFrame F = batch.f[fIdx];
     const int lane = threadIdx.x;
-    const int cx0 = blockIdx.x * VW, ry0 = blockIdx.y * bandRows;
+    const int cx0 = sIdx * VW, ry0 = bIdx * bandRows;
     const int colIn = cx0 - HALO + lane;              // the column this lane loads and differentiates
     const int gxIn = lk_mirror_index(colIn, width);   // (-width <= colIn < 2 width: width >= 64 is required)
     const int colOut = colIn - h;                     // the column whose window sum the Horner shifts leave in this lane
@@ -703,11 +717,19 @@ extern "C" int mfsr_lucasKanadeSweepBatch(int nFrames, const mfsr_lk_frame* fram
     band = (band + 4) & ~7;
     band = band < 8 ? 8 : (band > 64 ? 64 : band);
     if (forceBand >= 8) band = forceBand;
-    dim3 grid(strips, mfsr_cdiv(height, band), nFrames), block(64);
+    static const int xcdRemap = [] {
+        const char* e = getenv("MFSR_LK_XCD");
+        return e ? atoi(e) : 1;
+    }();
+    const int bands = mfsr_cdiv(height, band);
+    const int total = strips * bands * nFrames;
+    const int perXcd = xcdRemap ? mfsr_cdiv(total, 8) : 0;
+    // (remapped: a 1-D grid of 8 * perXcd workgroups whose .z still carries the frame count for the kernel's bound check)
+    dim3 grid = perXcd ? dim3(8 * perXcd, 1, 1) : dim3(strips, bands, nFrames), block(64);
 #define LKS_CASE(HT)                                                                                                          \
     case HT:                                                                                                                  \
         hipLaunchKernelGGL(k_lkSweep<HT>, grid, block, 0, mfsr_s(stream), b, refImg, pitchShift, pitchImg, pitchSD, width,    \
-                           height, minDet, outScale, band);                                                                   \
+                           height, minDet, outScale, band, strips, bands, perXcd, nFrames);                                   \
         break;
     switch (h) {
         LKS_CASE(1)
