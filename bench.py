@@ -322,17 +322,23 @@ def main():
     # MFSR_DIST_BACKEND=gloo: rehearsal of the multi-rank schedule on a box with fewer GPUs than ranks (the
     # ranks share GPUs, collectives are staged through the host); the measured runs use RCCL ("nccl")
     backend = os.environ.get("MFSR_DIST_BACKEND", "nccl")
-    if backend == "gloo":
+    if backend == "gloo" or args.virtual_ranks:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # The C-ABI multi-GPU path (libmfsr_dist.so) owns its RCCL communicator; torch.distributed is only the launcher's
+    # control plane there (unique-id broadcast, status / timing reductions, barriers) and runs on GLOO with host tensors, so
+    # that a failing RCCL (it has never run with more than one rank before the driver's own 8-GPU run) cannot take the
+    # control plane with it: the ranks then AGREE on the fallback below instead of dying one by one.
+    ctl_gloo = world > 1 and backend != "gloo" and args.dist_impl == "rccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "gloo":
+        if backend == "gloo" or ctl_gloo:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ctl_dev = torch.device("cpu") if ctl_gloo else dev     # where the control-plane tensors live
 
     from multi_frame_super_resolution_amd import distributed as mdist
     from multi_frame_super_resolution_amd.pipeline import BurstPipeline, default_config
@@ -388,6 +394,7 @@ def main():
     # --dist-impl local: all ranks of the burst in this process (mfsr_dist_group_*: one worker thread per rank inside the
     # library, peer copies over xGMI in place of RCCL calls; the same per-rank code as the RCCL contexts)
     grp = None
+    fallback_local = False     # set when the RCCL contexts could not be created and rank 0 took over with the in-process group
     if local_group:
         n_dev = torch.cuda.device_count()
         if not args.virtual_ranks and n_dev < n_ranks:
@@ -412,19 +419,62 @@ def main():
             buf = (ctypes.c_uint8 * capi.DIST_ID_BYTES)()
             D.dist_get_unique_id(buf)
             uid = torch.tensor(list(buf), dtype=torch.uint8)
-        uid = uid.to(dev)
+        uid = uid.to(ctl_dev)
         if world > 1:
             dist.broadcast(uid, src=0)
         uid_c = (ctypes.c_uint8 * capi.DIST_ID_BYTES)(*uid.cpu().tolist())
         nbytes = D.dist_workspace_bytes(ctypes.byref(cfg), world)
         d_ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
         d_h = ctypes.c_void_p()
-        D.dist_create(ctypes.byref(d_h), ctypes.byref(cfg), rank, world, uid_c, (d_ws.data_ptr() + 255) // 256 * 256, nbytes)
-        d_out16 = torch.empty(H * s, W * s, 3, dtype=torch.int16, device=dev) if rank == 0 else None
-        d_status = torch.zeros(1, dtype=torch.int32, device=dev)
-        d_ptrs = (ctypes.c_void_p * n_frames)(*[frames[k].data_ptr() if k in frames else None for k in range(n_frames)])
-        d_mode = {"stripes": capi.DIST_STRIPES, "reduce": capi.DIST_REDUCE, "reduce_scatter": capi.DIST_REDUCE_SCATTER}[exchange]
-        dctx = dict(D=D, h=d_h, burst=D.dist_burst(d_h))
+        created, why = 1, ""
+        try:
+            if os.environ.get("MFSR_BENCH_FAIL_RCCL") == "1":      # (test hook)
+                raise capi.MfsrError("mfsr_dist_create", -5, "MFSR_BENCH_FAIL_RCCL")
+            D.dist_create(ctypes.byref(d_h), ctypes.byref(cfg), rank, world, uid_c, (d_ws.data_ptr() + 255) // 256 * 256, nbytes)
+        except capi.MfsrError as e:
+            created, why = 0, str(e)
+        if world > 1:
+            ok = torch.tensor([created], dtype=torch.int32, device=ctl_dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            all_created = int(ok.item()) == 1
+        else:
+            all_created = created == 1
+        if not all_created:
+            # RCCL did not come up on every rank.  Agreed fallback (unless MFSR_BENCH_NO_FALLBACK=1): the ranks release their
+            # GPUs, rank 0 runs the same sharded burst with all ranks inside its own process (mfsr_dist_group_*, peer copies);
+            # the line says which transport ran and why.
+            msg = f"rank {rank}: mfsr_dist_create {'failed: ' + why if not created else 'ok, but a peer failed'}"
+            print("bench.py: " + msg, file=sys.stderr)
+            if created:
+                D.dist_destroy(d_h)
+            del d_ws
+            if world == 1 or os.environ.get("MFSR_BENCH_NO_FALLBACK") == "1" or not ctl_gloo:
+                raise SystemExit("bench.py: the RCCL contexts could not be created (" + msg + ")")
+            if rank != 0:
+                del frames
+                torch.cuda.empty_cache()
+                dist.barrier()           # rank 0's final barrier
+                dist.destroy_process_group()
+                return
+            os.environ["MFSR_BENCH_FALLBACK_FROM"] = "mfsr_dist_create failed on a rank (RCCL): " + (why or "see stderr")
+            use_cabi_dist, fallback_local = False, True
+            n_dev = torch.cuda.device_count()
+            if n_dev < n_ranks and not args.virtual_ranks:
+                raise SystemExit(f"fallback to the in-process group needs {n_ranks} visible devices, found {n_dev}")
+            g_devices = [0] * n_ranks if (args.virtual_ranks or n_dev < n_ranks) else list(range(n_ranks))
+            per_rank = [frames] + [rank_frames(r, torch.device("cuda", g_devices[r]))[1] for r in range(1, n_ranks)]
+            grp = mdist.LocalGroup(cfg, g_devices)
+            g_table = grp.frame_table(per_rank)
+            g_mode = exchange
+            args.no_e2e = True
+            for d_i in sorted(set(g_devices)):
+                torch.cuda.synchronize(d_i)
+        else:
+            d_out16 = torch.empty(H * s, W * s, 3, dtype=torch.int16, device=dev) if rank == 0 else None
+            d_status = torch.zeros(1, dtype=torch.int32, device=dev)
+            d_ptrs = (ctypes.c_void_p * n_frames)(*[frames[k].data_ptr() if k in frames else None for k in range(n_frames)])
+            d_mode = {"stripes": capi.DIST_STRIPES, "reduce": capi.DIST_REDUCE, "reduce_scatter": capi.DIST_REDUCE_SCATTER}[exchange]
+            dctx = dict(D=D, h=d_h, burst=D.dist_burst(d_h))
 
     # torch.distributed mirror, accumulator-summing modes: steps are independent bursts, so the exchange (reduce-scatter,
     # stripe finish, gather) of burst i runs on a side stream while the compute stream already aligns and fuses burst i+1
@@ -501,7 +551,7 @@ def main():
         if h2d:
             pipe.host_sync()      # the last image's download runs on the burst's own stream
 
-    if world > 1:  # bring the RCCL communicator up outside the timed region even with --warmup 0
+    if world > 1 and not ctl_gloo:  # (torch mirror) bring torch's RCCL communicator up outside the timed region even with --warmup 0
         dist.all_reduce(torch.zeros(1, device=dev))
     for _ in range(args.warmup):
         step()
@@ -532,7 +582,7 @@ def main():
         if args.warmup == 0:
             step()
             barrier()
-        st = d_status.clone()
+        st = d_status.clone().to(ctl_dev)
         if world > 1:
             dist.all_reduce(st, op=dist.ReduceOp.MAX)
         if int(st.item()) != 0:
@@ -590,8 +640,8 @@ def main():
         if last is not None:
             out16_sha = hashlib.sha256(last.cpu().numpy().tobytes()).hexdigest()[:16]
 
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1 and not fallback_local:
+        t = torch.tensor([dt], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if grp is not None and any(int(t.item()) != 0 for t in grp.status):
@@ -759,7 +809,7 @@ def main():
                      + (" overlapped with the next burst's compute" if pipelined else ""))
                     + (", libmfsr_dist.so, one process per GPU (RCCL directly)" if use_cabi_dist else
                        (", libmfsr_dist.so, all ranks in one process (mfsr_dist_group: one thread per rank, peer copies)"
-                        + (", ALL RANKS ON DEVICE 0: rehearsal, not a measurement" if args.virtual_ranks else "")
+                        + (", ALL RANKS ON DEVICE 0: rehearsal, not a measurement" if (args.virtual_ranks or (grp is not None and len(set(grp.devices)) < n_ranks)) else "")
                         if grp is not None else ", torch.distributed mirror"))
                     + (f"; {halo_note}" if halo_note else "")
                     + (f"; fallback: {os.environ['MFSR_BENCH_FALLBACK_FROM']}" if os.environ.get("MFSR_BENCH_FALLBACK_FROM") else "")),

@@ -226,3 +226,33 @@ def test_bench_child_process_path_with_a_one_rank_rccl_context():
     e = json.loads([l for l in q.stdout.splitlines() if l.strip().startswith("{")][0])
     assert e["transport"] is None
     assert d["out16_sha256_16"] == e["out16_sha256_16"] and d["out16_sha256_16"]
+
+
+def test_bench_ranks_agree_on_the_in_process_fallback_when_rccl_does_not_come_up():
+    """The driver's N > 1 command is the first run of the RCCL back end with more than one rank.  If mfsr_dist_create fails
+    on any rank (here: forced on every rank, MFSR_BENCH_FAIL_RCCL=1), the ranks agree over the gloo control plane, the
+    others release their GPUs and park at the final barrier, and rank 0 measures the same sharded burst with all ranks
+    inside its own process (mfsr_dist_group_*): rc 0, one line, transport 'local (fallback: ...)', and -- the stripes mode
+    being bit-identical -- the checksum of the one-GPU run.  (Two ranks on the one device: --virtual-ranks, a rehearsal.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--steps", "2", "--warmup", "1", "--workload", "1080p5_gray_x2", "--no-cpu-baseline", "--no-e2e", "--no-isolated"]
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-impl", "rccl", "--virtual-ranks"] + common,
+                       env=dict(env, MFSR_BENCH_FAIL_RCCL="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["transport"].startswith("local (fallback:") and d["n_gpus"] == 2 and d["value"] > 0
+    assert "rehearsal" in d["config"]["parallelism"]
+    q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert q.returncode == 0, q.stderr[-2000:]
+    e = json.loads([l for l in q.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["out16_sha256_16"] == e["out16_sha256_16"] and e["out16_sha256_16"]
