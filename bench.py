@@ -479,11 +479,11 @@ def main():
     # torch.distributed mirror, accumulator-summing modes: steps are independent bursts, so the exchange (reduce-scatter,
     # stripe finish, gather) of burst i runs on a side stream while the compute stream already aligns and fuses burst i+1
     # into a second burst context (own workspace + accumulators): collectives overlap compute.
-    pipelined = ((world > 1 and not args.no_overlap and not use_cabi_dist and exchange != "stripes") or args.force_pipelined)
+    pipelined = ((world > 1 and not args.no_overlap and not use_cabi_dist and exchange != "stripes" and grp is None) or args.force_pipelined)
     pipes = [pipe] if pipe is not None else []
     step_no = [0]
     stripe_bufs = None
-    if world > 1 and not use_cabi_dist and exchange == "stripes":
+    if world > 1 and not use_cabi_dist and exchange == "stripes" and grp is None:
         stripe_bufs = mdist.StripeBuffers(pipe, n_frames, rank, world)
     if pipelined:
         pipes.append(BurstPipeline(cfg, dev))
@@ -737,7 +737,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "fuse_traffic.json")
         if os.path.exists(tpath):
             try:
-                ent = json.load(open(tpath)).get(args.workload)
+                tj = json.load(open(tpath))
+                # (the 64-frame 8K burst launches the very kernel instance on the very grid of its 8-frame share)
+                ent = tj.get(args.workload) or (tj.get("8k8_rggb_x2") if args.workload == "8k64_rggb_x2" else None)
                 # the counters describe one state of the kernel sources: an entry taken from another state is not reported
                 import hashlib
                 hsh = hashlib.sha256()
