@@ -263,9 +263,10 @@ def main():
     ap.add_argument("--no-pair", action="store_true", help="cfg.pairFrames = 0: one warp+fuse launch per frame (the reference's structure)")
     ap.add_argument("--group", type=int, default=None, help="cfg.pairFrames = N: N frames per warp+fuse launch (2..4; default: as many as "
                     "one launch takes, 4 at x2 Bayer, else 2)")
-    ap.add_argument("--async-fuse", action="store_true", help="(default since round 2: cfg.asyncFuse = 1) accepted for compatibility")
-    ap.add_argument("--no-async-fuse", action="store_true",
-                    help="cfg.asyncFuse = 0: warp+fuse launches on the caller's stream instead of the burst's own (A/B: -5 %%)")
+    ap.add_argument("--async-fuse", action="store_true",
+                    help="cfg.asyncFuse = 1: warp+fuse launches on the burst's own stream beside the alignment of the next group (the "
+                         "default of rounds 2-3; measured 1 %% slower than one stream since the fuse kernel fills the CUs: A/B)")
+    ap.add_argument("--no-async-fuse", action="store_true", help="(default since round 4: cfg.asyncFuse = 0) accepted for compatibility")
     ap.add_argument("--h2d", action="store_true",
                     help="N=1 only: frames start in pinned HOST memory and stream through a 4-deep device ring on a copy "
                          "stream (the PCIe-inclusive rate quoted in DESIGN.md; `value` of the contract is the HBM-resident run)")
@@ -356,6 +357,8 @@ def main():
         cfg.pairFrames = args.group
     if args.no_async_fuse:
         cfg.asyncFuse = 0
+    if args.async_fuse:
+        cfg.asyncFuse = 1
     if world == 1 and not local_group:
         # device slots for --h2d and the end-to-end leg (mfsr_burst_*_host); unused by the resident run.  16 slots: a whole
         # 16-frame burst uploads without waiting for a slot (11.2 ms per 4K burst incl. the download of the result, against
@@ -650,7 +653,7 @@ def main():
         raise SystemExit("mfsr_dist: a frame's vertical flow exceeded the raw halo of the stripes exchange (status 1): the result is "
                          "invalid; use --exchange reduce_scatter or a larger halo")
 
-    # The timed region runs with cfg.asyncFuse (the default): the warp+fuse launches share the GPU with the alignment of the
+    # With cfg.asyncFuse (--async-fuse; not the default any more) the warp+fuse launches share the GPU with the alignment of the
     # following frames, which stretches them.  A short extra leg times the same launches WITHOUT that overlap (launches back to
     # back on one stream) so that the line also carries the kernel's stand-alone figure.
     isolated = None

@@ -497,8 +497,10 @@ typedef struct {
     int32_t pairFrames;      /* frames per warp+fuse launch of add_frame (see mfsr_burst_add_frame): 0 = one, like the
                                 reference; 1 (default) = as many as one launch takes (MFSR_MAX_FUSE_GROUP at scale 2 and 4 Bayer, else 2);
                                 2 .. MFSR_MAX_FUSE_GROUP = that many */
-    int32_t asyncFuse;       /* 1 (default): the warp+fuse launches run on a stream owned by the burst, concurrently with the
-                                alignment of the following frames on the caller's stream (see mfsr_burst_add_frame) */
+    int32_t asyncFuse;       /* 1: the warp+fuse launches run on a stream owned by the burst, beside the alignment of the
+                                following frames on the caller's stream (see mfsr_burst_add_frame); 0 (default since round 4:
+                                the four-workgroup fuse kernel leaves no room on a CU for the alignment to run beside it, so
+                                one stream is 1 % faster): everything on the caller's stream.  Same bits either way. */
     int32_t preAlign;        /* 1: estimate a global base shift + rotation per moved frame (mfsr_preAlign) and feed it to
                                 the tile tracker and the flow field (baseShift / baseRotation of kernel.cu:324, opticalFlow.cu:48) */
     float preAlignMaxAngle;  /* search range of the base rotation in degrees (default 20) */

@@ -413,8 +413,11 @@ extern "C" int mfsr_config_default(mfsr_config* cfg, int width, int height, int 
     cfg->pairFrames = 1;
     cfg->preAlign = 0;   // opt-in: bursts with rotations / shifts beyond the tile tracker's reach (the bundled "city" burst)
     cfg->preAlignMaxAngle = 20.0f;
-    cfg->asyncFuse = 1;  // warp+fuse of frames k, k+1 overlaps the alignment of k+2, k+3 on a burst-owned stream: +5 % burst
-                         // throughput (7.85 vs 8.27 ms per 16-frame 4K burst), bit-identical results
+    cfg->asyncFuse = 0;  // 1: warp+fuse launches on a burst-owned stream beside the alignment of the next group.  It paid +5 % in
+                         // round 2; since the fuse kernel keeps four 128-VGPR workgroups per CU (round 3) nothing of the alignment
+                         // gets onto a CU beside it -- the two streams alternate -- and the fork / join events cost more than
+                         // the overlap returns: 5.97 ms per 4K x 16 burst on one stream against 6.03 on two (interleaved A/B,
+                         // profiles/r04_async_fuse_ab.txt).  Off by default since round 4; bit-identical either way.
     return MFSR_OK;
 }
 

@@ -67,7 +67,7 @@ def test_argument_validation_happens_on_the_host():
                                                None) == -1
     cfgd = capi.Config()
     assert raw["mfsr_config_default"](ctypes.byref(cfgd), 256, 192, 4, 2, 0) == 0
-    assert cfgd.pairFrames == 1 and cfgd.asyncFuse == 1 and cfgd.preAlign == 0 and cfgd.uploadRing == 0
+    assert cfgd.pairFrames == 1 and cfgd.asyncFuse == 0 and cfgd.preAlign == 0 and cfgd.uploadRing == 0
     assert L.raw["mfsr_error_string"](-1) == b"invalid argument"
     assert L.raw["mfsr_error_string"](0) == b"success"
 

@@ -400,15 +400,15 @@ def test_config2_4k_rggb_x2_sample_vs_oracle():
 
 def test_config2_full_burst_16_frames_4k_vs_oracle():
     """BASELINE configs[2] AS STATED: the whole 16-frame 3840x2160 RGGB burst, x2, default configuration (groups of four frames
-    per warp+fuse launch, cfg.asyncFuse, the rings of eight flow / mask slots cycling twice, launches 2..4 accumulating on top
-    of the first one's overwrite) against the oracle -- every frame's flow and mask enter the flip-set classification, the
+    per warp+fuse launch, the rings of eight flow / mask slots cycling twice, launches 2..4 accumulating on top of the first
+    one's overwrite) against the oracle -- every frame's flow and mask enter the flip-set classification, the
     full +-1 LSB contract and the flow-difference localisation hold.  (~25 s of oracle on the box's host cores.)"""
     import time
     from multi_frame_super_resolution_amd.synth import make_burst
     W, H, N = 3840, 2160, 16
     frames, shifts, _ = make_burst(W, H, N, scale=2, mono=False, seed=1234 + 2)
     cfg = _cfg(W, H, N, 2, False, 1)
-    assert cfg.asyncFuse == 1 and cfg.pairFrames == 1
+    assert cfg.asyncFuse == 0 and cfg.pairFrames == 1      # the defaults bench.py measures
     h = run_hip(cfg, frames)
     t0 = time.time()
     o = run_oracle(cfg, frames)
