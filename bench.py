@@ -775,8 +775,7 @@ def main():
                                 "cycles_per_inst_note": ("class-weighted issue cost of the kernel's static instruction mix "
                                                          f"({ent.get('valu_mix_static')}; fast 2.8 / slow 4.4 / transcendental 8.3 cycles, "
                                                          "tools/ubench/valu_ops.hip)") if cpw else "nominal 4 cycles (no instruction mix recorded)",
-                                "nominal_4_cycles": {"floor_ms": round(nominal_ms, 4),
-                                                     "frac": round(nominal_ms / k_ms, 4) if k_ms > 0 else None},
+                                "nominal_4_cycles_floor_ms": round(nominal_ms, 4),   # (not a floor: the fast class issues at 2.8 cycles)
                                 "source": ent.get("source")}
                 elif ent is not None:
                     traffic = ent
