@@ -1618,7 +1618,20 @@ static int upload_into(mfsr_burst* b, int us, uint16_t* dst, const uint16_t* hos
         MFSR_HIP_TRY(hipStreamWaitEvent(b->copyStream, b->evFree[us], 0));
         b->freeRecorded[us] = false;
     }
-    MFSR_HIP_TRY(hipMemcpyAsync(dst, hostRaw, (size_t)b->L.W * b->L.H * 2, hipMemcpyHostToDevice, b->copyStream));
+    // A 2-D copy, like the download (mfsr_burst_finish_host): measured on this ROCm (tools/pcie_duplex2.py,
+    // profiles/r04_pcie_duplex_mechanisms.txt), 1-D uploads queued against 2-D downloads SERIALISE -- 16 uploads + one image:
+    // 8.38 ms, the sum of the two directions alone -- while 2-D uploads and 2-D downloads overlap on the full-duplex link:
+    // 4.85 ms = the uploads alone.  (A 1-D download would overlap too, but it is a blit kernel whose PCIe-bound stores slow
+    // the fuse launches 4-5x.)  MFSR_UPLOAD_1D=1: the round-3 form (A/B).
+    static const bool up1d = [] {
+        const char* e = getenv("MFSR_UPLOAD_1D");
+        return e && e[0] == '1';
+    }();
+    if (up1d)
+        MFSR_HIP_TRY(hipMemcpyAsync(dst, hostRaw, (size_t)b->L.W * b->L.H * 2, hipMemcpyHostToDevice, b->copyStream));
+    else
+        MFSR_HIP_TRY(hipMemcpy2DAsync(dst, (size_t)b->L.W * 2, hostRaw, (size_t)b->L.W * 2, (size_t)b->L.W * 2, (size_t)b->L.H,
+                                      hipMemcpyHostToDevice, b->copyStream));
     MFSR_HIP_TRY(hipEventRecord(b->evUp[us], b->copyStream));
     MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evUp[us], 0));
     return MFSR_OK;
@@ -2089,7 +2102,9 @@ extern "C" int mfsr_stream_push(mfsr_stream* s, const uint16_t* frame, mfsr_floa
         // the slot held frame t - cap, last read by output t - cap + R = t - R - 1
         const long long last = t - s->R - 1;
         if (last >= 0 && s->windowRecorded[last % 64]) MFSR_HIP_TRY(hipStreamWaitEvent(s->copyStream, s->evWindow[last % 64], 0));
-        MFSR_HIP_TRY(hipMemcpyAsync(f.raw, frame, rawBytes, hipMemcpyHostToDevice, s->copyStream));
+        // (2-D, like mfsr_burst_add_frame_host's uploads: overlaps with the 2-D downloads of a caller's results)
+        MFSR_HIP_TRY(hipMemcpy2DAsync(f.raw, (size_t)L.W * 2, frame, (size_t)L.W * 2, (size_t)L.W * 2, (size_t)L.H, hipMemcpyHostToDevice,
+                                      s->copyStream));
         MFSR_HIP_TRY(hipEventRecord(s->evUp, s->copyStream));
         MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), s->evUp, 0));
     } else {

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Is the host link full duplex for the traffic of back-to-back host bursts?  Per 4K x 16 burst the library uploads
-16 x 16.6 MB (hipMemcpyAsync H2D from pinned memory, copy stream) and downloads one 199 MB u16 image (hipMemcpy2DAsync D2H in
-8 row bands: SDMA).  Measures both directions alone and together, as the library issues them."""
+"""The copy pattern of round 3's host bursts: per 4K x 16 burst 16 x 16.6 MB up as 1-D hipMemcpyAsync calls and one 199 MB u16
+image down as 2-D hipMemcpy2DAsync bands.  Both directions alone and together.  (This combination SERIALISES on this ROCm --
+8.4 ms, the sum -- although the link is full duplex: tools/pcie_duplex2.py compares the mechanisms; the library's uploads are
+2-D copies since.)"""
 import ctypes
 import json
 import time
@@ -58,4 +59,4 @@ a, b, c = run(True, False), run(False, True), run(True, True)
 print(json.dumps({"upload_only_ms_per_burst": round(a, 3), "upload_GBps": round(up_mb / a, 1), "download_only_ms_per_burst": round(b, 3),
                   "download_GBps": round(down_mb / b, 1), "both_ms_per_burst": round(c, 3), "both_total_GBps": round((up_mb + down_mb) / c, 1),
                   "upload_mb": up_mb, "download_mb": down_mb,
-                  "note": "back-to-back host bursts cannot run faster than both_ms_per_burst: the floor the link sets"}))
+                  "note": "1-D uploads queued against 2-D downloads: serialised on this ROCm (see tools/pcie_duplex2.py)"}))
