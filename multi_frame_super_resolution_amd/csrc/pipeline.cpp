@@ -335,6 +335,8 @@ struct mfsr_burst {
     hipEvent_t evUp[kMaxUploadRing + 2];    // upload of the slot complete (copy stream); [ring..ring+1] = reference slots
     hipEvent_t evFree[kMaxUploadRing + 2];  // last consumer of the slot enqueued (compute / fuse stream)
     bool freeRecorded[kMaxUploadRing + 2];
+    bool upPending;                         // uploads were enqueued that the compute stream has not been made to wait for yet
+    int upPendingSlot;                      // ... the LAST of them (the copy stream is in order: its event covers the earlier ones)
     int refSlot;                            // upload slot of the current host reference (-1: none / released)
     bool hostBusy;                          // this host burst was enqueued before the previous one's download had finished
     int upCounter, refCounter;
@@ -511,6 +513,8 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     b->refHost = b->refDev = nullptr;
     b->refSlot = -1;
     b->hostBusy = false;
+    b->upPending = false;
+    b->upPendingSlot = -1;
     for (int i = 0; i < kMaxUploadRing + 2; i++) {
         b->evUp[i] = b->evFree[i] = nullptr;
         b->freeRecorded[i] = false;
@@ -596,6 +600,16 @@ extern "C" int mfsr_burst_timing_read(mfsr_burst* b, double* totalMs, int* launc
     return MFSR_OK;
 }
 
+// host-frame bursts: `stream` is about to read raw frames the copy stream uploads -- wait for the last upload enqueued so far
+static int wait_uploads(mfsr_burst* b, mfsr_stream_t stream)
+{
+    if (b->upPending) {
+        MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evUp[b->upPendingSlot], 0));
+        b->upPending = false;
+    }
+    return MFSR_OK;
+}
+
 // A1 + tracking pyramid for one frame (shared by reference and moved frames)
 static int prepare_frame(mfsr_burst* b, const uint16_t* raw, Img& half, Img* pyr, mfsr_stream_t stream)
 {
@@ -640,6 +654,7 @@ static int set_reference_impl(mfsr_burst* b, const uint16_t* rawRef, int hrRow0,
     Layout& L = b->L;
     MFSR_REQUIRE(hrRow0 >= 0 && hrRow1 > hrRow0 && hrRow1 <= L.hrH);
     const bool whole = (hrRow0 == 0 && hrRow1 == L.hrH) || !c.fused;  // (the unfused chain always makes whole images)
+    TRY(wait_uploads(b, stream));
     if (!b->refPrepared) TRY(prepare_frame(b, rawRef, L.refHalf, L.refPyr, stream));
     if (c.fused)
         for (int l = 0; l < c.levels; l++) {
@@ -846,6 +861,7 @@ static int accumulate_pending(mfsr_burst* b, mfsr_stream_t callerStream)
 {
     TRY(fuse_held(b, callerStream));       // it comes before the frames that arrived after it
     TRY(align_deferred(b, callerStream));  // frames of the group that were waiting for their batch
+    TRY(wait_uploads(b, callerStream));    // (a reference frame of the group is read by the fuse only)
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
     const mfsr_burst::Pending p = b->pend;
@@ -969,6 +985,7 @@ static int align_frame(mfsr_burst* b, const uint16_t* raw, int isReference, int 
 {
     const mfsr_config& c = b->cfg;
     Layout& L = b->L;
+    TRY(wait_uploads(b, stream));
     // the slot's buffers are free once the fuse that read them last has run
     if ((phases & ALIGN_PRE) && b->fuseStream && b->fusedOutstanding[slot]) {
         MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evFused[slot], 0));
@@ -1147,6 +1164,7 @@ static int align_deferred(mfsr_burst* b, mfsr_stream_t stream)
     for (int i = 0; i < b->pend.n; i++)
         if (b->pend.deferred[i]) idx[n++] = i;
     if (n == 0) return MFSR_OK;
+    TRY(wait_uploads(b, stream));
     // the moved-frame intermediates of batch position q (0: the Layout's own members, q > 0: align set q - 1)
     auto movHalf = [&](int q) -> Img& { return q == 0 ? L.movHalf : L.sets[q - 1].movHalf; };
     auto movPyr = [&](int q) -> Img* { return q == 0 ? L.movPyr : L.sets[q - 1].movPyr; };
@@ -1633,7 +1651,13 @@ static int upload_into(mfsr_burst* b, int us, uint16_t* dst, const uint16_t* hos
         MFSR_HIP_TRY(hipMemcpy2DAsync(dst, (size_t)b->L.W * 2, hostRaw, (size_t)b->L.W * 2, (size_t)b->L.W * 2, (size_t)b->L.H,
                                       hipMemcpyHostToDevice, b->copyStream));
     MFSR_HIP_TRY(hipEventRecord(b->evUp[us], b->copyStream));
-    MFSR_HIP_TRY(hipStreamWaitEvent(mfsr_s(stream), b->evUp[us], 0));
+    // the compute stream waits for it when the first kernel that reads an uploaded frame is about to be enqueued
+    // (wait_uploads): ONE wait for the last upload of a group instead of one per frame -- a cross-queue wait costs the
+    // compute queue ~15 us even when it is already satisfied (four in a row before a group's first kernel: 55-68 us in the
+    // trace of back-to-back bursts)
+    (void)stream;
+    b->upPending = true;
+    b->upPendingSlot = us;
     return MFSR_OK;
 }
 
@@ -1730,6 +1754,15 @@ extern "C" int mfsr_burst_finish_host(mfsr_burst* b, const mfsr_float3* imgOut, 
         return e ? atoi(e) : 8;
     }();
     int nBands = nBandsEnv < 1 ? 1 : (nBandsEnv > 16 ? 16 : nBandsEnv);
+    // The bands exist for the LATENCY of one burst (its download starts after 1/8 of the tail).  A burst that was enqueued
+    // while the previous one's download was still in flight (b->hostBusy: bursts back to back) gains nothing from them -- its
+    // download runs under the next burst's compute anyway -- and pays 16 band-sized fuse launches + 8 finish launches for it:
+    // such a burst takes MFSR_HOST_BANDS_BUSY bands (default 2).
+    static const int nBandsBusy = [] {
+        const char* e = getenv("MFSR_HOST_BANDS_BUSY");
+        return e ? atoi(e) : 2;
+    }();
+    if (b->hostBusy && nBandsBusy >= 1 && nBandsBusy < nBands) nBands = nBandsBusy;
     bool heldGroup = b->pend.n > 0 && b->pend.imgOut == imgOut && b->pend.totalWeights == totalWeights && c.fused;
     if (b->heldHas && !(heldGroup && b->held.imgOut == imgOut && b->held.totalWeights == totalWeights)) {
         TRY(flush_pending(b, stream));  // a held group without the last one, or other accumulators: the ordinary way
