@@ -568,6 +568,14 @@ int mfsr_burst_finish_rows(mfsr_burst* b, const mfsr_float3* imgOut, const mfsr_
 int mfsr_burst_set_reference_host(mfsr_burst* b, const uint16_t* hostRaw, mfsr_stream_t stream);
 int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw, int isReference, mfsr_float3* imgOut,
                               mfsr_float3* totalWeights, mfsr_stream_t stream);
+/* Optional: enqueue the uploads of the next nFrames frames (in the order they will be handed to add_frame_host) right
+ * away, before any of their kernels.  add_frame_host enqueues a frame's ~10 alignment launches after its copy, so the NEXT
+ * frame's copy reaches the copy engine only when the host is through with those -- 16 us between copies most of the time,
+ * 70-300 us at group boundaries (one burst at 4K x 16: the uploads end at 5.7 instead of 5.0 ms).  With the copies queued up
+ * front the engine runs them back to back and every add_frame_host finds its frame already on its way (matched by the
+ * host pointer; a frame that was not announced is uploaded as before).  At most cfg.uploadRing frames are taken, the
+ * pointer of the current host reference is skipped; call it after set_reference_host. */
+int mfsr_burst_prefetch_host(mfsr_burst* b, const uint16_t* const* hostRaws, int nFrames, mfsr_stream_t stream);
 /* mfsr_burst_finish into out16Dev (device), then its D2H copy into out16Host on a stream the burst owns, so that the next
  * burst's uploads and kernels overlap the download (full-duplex PCIe).  out16Host is complete after
  * mfsr_burst_host_sync(b) (blocks the HOST on the download); out16Dev must not be written by the caller before that. */

@@ -335,6 +335,12 @@ struct mfsr_burst {
     hipEvent_t evUp[kMaxUploadRing + 2];    // upload of the slot complete (copy stream); [ring..ring+1] = reference slots
     hipEvent_t evFree[kMaxUploadRing + 2];  // last consumer of the slot enqueued (compute / fuse stream)
     bool freeRecorded[kMaxUploadRing + 2];
+    // mfsr_burst_prefetch_host: frames whose upload is already enqueued, in order; consumed by add_frame_host
+    struct Prefetched {
+        const uint16_t* host;
+        int slot;
+    } prefetched[kMaxUploadRing];
+    int nPrefetched, prefetchHead;
     bool upPending;                         // uploads were enqueued that the compute stream has not been made to wait for yet
     int upPendingSlot;                      // ... the LAST of them (the copy stream is in order: its event covers the earlier ones)
     int refSlot;                            // upload slot of the current host reference (-1: none / released)
@@ -515,6 +521,7 @@ extern "C" int mfsr_burst_create(mfsr_burst** out, const mfsr_config* cfg, void*
     b->hostBusy = false;
     b->upPending = false;
     b->upPendingSlot = -1;
+    b->nPrefetched = b->prefetchHead = 0;
     for (int i = 0; i < kMaxUploadRing + 2; i++) {
         b->evUp[i] = b->evFree[i] = nullptr;
         b->freeRecorded[i] = false;
@@ -1688,6 +1695,7 @@ extern "C" int mfsr_burst_set_reference_host(mfsr_burst* b, const uint16_t* host
         b->freeRecorded[us] = true;
     }
     b->refSlot = us;
+    b->nPrefetched = b->prefetchHead = 0;
     TRY(upload_into(b, us, b->L.refRaw[i], hostRaw, stream));
     b->refHost = hostRaw;
     b->refDev = b->L.refRaw[i];
@@ -1705,6 +1713,16 @@ extern "C" int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw,
     }();
     if (isReference && hostRaw == b->refHost && b->refDev)
         return add_frame_impl(b, b->refDev, 1, imgOut, totalWeights, banded, stream);
+    if (b->prefetchHead < b->nPrefetched) {
+        // announced by mfsr_burst_prefetch_host: the copy is already on the copy stream
+        if (b->prefetched[b->prefetchHead].host == hostRaw) {
+            const int ps = b->prefetched[b->prefetchHead++].slot;
+            b->upPending = true;        // this frame's kernels wait for THIS frame's copy (the copy stream is in order)
+            b->upPendingSlot = ps;
+            return add_frame_impl(b, b->L.rawRing[ps], isReference, imgOut, totalWeights, banded, stream);
+        }
+        b->nPrefetched = b->prefetchHead = 0;  // another order than announced: the remaining copies are simply not used
+    }
     const int us = b->upCounter++ % b->cfg.uploadRing;
     // a ring shorter than the fuse group: the slot may still hold a frame that waits for the rest of its group
     bool waiting = false, waitingHeld = false;
@@ -1716,6 +1734,26 @@ extern "C" int mfsr_burst_add_frame_host(mfsr_burst* b, const uint16_t* hostRaw,
         TRY(fuse_held(b, stream));  // only the held group: the frames waiting after it keep their group
     TRY(upload_into(b, us, b->L.rawRing[us], hostRaw, stream));
     return add_frame_impl(b, b->L.rawRing[us], isReference, imgOut, totalWeights, banded, stream);
+}
+
+extern "C" int mfsr_burst_prefetch_host(mfsr_burst* b, const uint16_t* const* hostRaws, int nFrames, mfsr_stream_t stream)
+{
+    MFSR_REQUIRE(b && hostRaws && nFrames >= 0);
+    MFSR_REQUIRE(b->copyStream != nullptr);
+    b->nPrefetched = b->prefetchHead = 0;
+    // only at the start of a burst: no frame may be waiting in a slot the copies would overwrite
+    if (b->pend.n > 0 || b->heldHas) return MFSR_OK;
+    for (int k = 0; k < nFrames && b->nPrefetched < b->cfg.uploadRing; k++) {
+        MFSR_REQUIRE(hostRaws[k] != nullptr);
+        if (hostRaws[k] == b->refHost && b->refDev) continue;   // add_frame_host re-uses the uploaded reference
+        const int us = b->upCounter++ % b->cfg.uploadRing;
+        TRY(upload_into(b, us, b->L.rawRing[us], hostRaws[k], stream));
+        b->prefetched[b->nPrefetched].host = hostRaws[k];
+        b->prefetched[b->nPrefetched].slot = us;
+        b->nPrefetched++;
+    }
+    b->upPending = false;   // (every consumer sets its own wait in add_frame_host)
+    return MFSR_OK;
 }
 
 // finish + download in row bands.  What is still waiting to be fused (normally the burst's last group, held back by

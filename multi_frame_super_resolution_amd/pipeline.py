@@ -203,6 +203,10 @@ class BurstPipeline:
         self.begin_burst()
         ref = self.cfg.reference
         self.L.burst_set_reference_host(self._h, host_frames[ref].data_ptr(), st)
+        # every copy queued before the first kernel: the copy engine then runs them back to back (mfsr_burst_prefetch_host)
+        n = len(host_frames)
+        ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in host_frames])
+        self.L.burst_prefetch_host(self._h, ptrs, n, st)
         for k, f in enumerate(host_frames):
             self.L.burst_add_frame_host(self._h, f.data_ptr(), 1 if k == ref else 0, self._img_out.data_ptr(),
                                         self._total_weights.data_ptr(), st)

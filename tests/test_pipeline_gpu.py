@@ -566,6 +566,46 @@ def test_host_frame_burst_equals_device_frame_burst(ring, pair, async_fuse):
         pipe.close()
 
 
+@pytest.mark.parametrize("ring,announce", [(16, "reversed"), (16, "partial"), (4, "all"), (16, "with_reference")])
+def test_host_burst_prefetch_announcements_that_do_not_match(ring, announce):
+    """mfsr_burst_prefetch_host queues the uploads of the announced frames up front; add_frame_host matches them by host
+    pointer IN ORDER.  Frames that come in another order than announced, only partly announced, announced with a ring
+    shorter than the burst, or announced together with the reference's own pointer must still give the resident burst's
+    image (an unmatched announcement is a wasted copy, never a wrong frame)."""
+    import torch
+    from multi_frame_super_resolution_amd import synth
+    from multi_frame_super_resolution_amd.pipeline import BurstPipeline, default_config
+    dev = torch.device("cuda:0")
+    W, H, N = 384, 256, 9
+    frames, _, _ = synth.make_burst(W, H, N, seed=61, device="cpu")
+    cfg = default_config(W, H, N, scale=2)
+    cfg.reference = 1
+    plain = BurstPipeline(cfg, dev)
+    _, want = plain.process([f.to(dev) for f in frames])
+    want = want.cpu().clone()
+    plain.close()
+    cfg.uploadRing = ring
+    pipe = BurstPipeline(cfg, dev)
+    pinned = [f.pin_memory() for f in frames]
+    out_host = torch.zeros(H * 2, W * 2, 3, dtype=torch.int16).pin_memory()
+    st = torch.cuda.current_stream().cuda_stream
+    for rep in range(2):
+        pipe.begin_burst()
+        pipe.L.burst_set_reference_host(pipe._h, pinned[cfg.reference].data_ptr(), st)
+        ann = {"reversed": pinned[::-1], "partial": pinned[:4], "all": pinned, "with_reference": pinned}[announce]
+        ptrs = (ctypes.c_void_p * len(ann))(*[f.data_ptr() for f in ann])
+        pipe.L.burst_prefetch_host(pipe._h, ptrs, len(ann), st)
+        for k, f in enumerate(pinned):
+            pipe.L.burst_add_frame_host(pipe._h, f.data_ptr(), 1 if k == cfg.reference else 0, pipe._img_out.data_ptr(),
+                                        pipe._total_weights.data_ptr(), st)
+        pipe.L.burst_finish_host(pipe._h, pipe._img_out.data_ptr(), pipe._total_weights.data_ptr(), pipe.out16.data_ptr(),
+                                 out_host.data_ptr(), st)
+        pipe.host_sync()
+        assert torch.equal(out_host, want), (ring, announce, rep)
+        out_host.zero_()
+    pipe.close()
+
+
 @pytest.mark.parametrize("ring,group", [(32, 4), (9, 4), (5, 2), (16, 3)])
 def test_host_bursts_back_to_back_equal_single_bursts(ring, group):
     """Host bursts enqueued back to back with NO host synchronisation between them (the next burst's uploads run under
