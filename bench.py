@@ -776,6 +776,9 @@ def main():
                                                          f"({ent.get('valu_mix_static')}; fast 2.8 / slow 4.4 / transcendental 8.3 cycles, "
                                                          "tools/ubench/valu_ops.hip)") if cpw else "nominal 4 cycles (no instruction mix recorded)",
                                 "nominal_4_cycles_floor_ms": round(nominal_ms, 4),   # (not a floor: the fast class issues at 2.8 cycles)
+                                # every instruction at the fastest class's cost: a bound no mix can beat (the weighted figure above
+                                # prices a STATIC mix and is good to a few percent)
+                                "all_fast_class_floor_ms": round(vi * 2.8 / (1024 * VALU_CLOCK_GHZ * 1e9) * 1e3, 4),
                                 "source": ent.get("source")}
                 elif ent is not None:
                     traffic = ent
