@@ -8,8 +8,12 @@ LR-sized); ``imgOut`` / ``totalWeights`` are plain sums over frames
 sum of the HR accumulators.  The reference itself is single-GPU
 (``cudaSetDevice(0)``, kernel.cu:45): this module is new work.
 
-Three exchange modes (``stripes`` is what ``include/mfsr_dist.h`` / ``csrc/dist.cpp`` do with RCCL directly; this
-module is the torch.distributed mirror over the same C-ABI building blocks, which the world-2 tests drive with gloo):
+THE PRODUCT IS ``csrc/dist.cpp`` (``include/mfsr_dist.h``: RCCL or in-process peer copies behind one transport table,
+pipelined bursts, packed messages with 3-float certainties, measured raw halo, early stripe gather).  This module is its
+torch.distributed MIRROR over the same C-ABI building blocks: the plain schedule without those refinements, kept for two
+purposes only -- the world-2 gloo tests on the CPU (``tests/test_distributed_gloo.py``, driven through a stand-in pipe) and
+``bench.py --dist-impl torch`` / ``MFSR_DIST_BACKEND=gloo`` rehearsals -- plus ``LocalGroup``, the ctypes wrapper of
+``mfsr_dist_group_*``.  Three exchange modes:
 
 ``stripes``         (default) the FUSE stage is sharded over HR row stripes instead of over frames: every rank aligns
                     its own frames, sends each peer the rows of raw / flow / certainty that the peer's stripe reads
