@@ -554,6 +554,24 @@ def main():
         if h2d:
             pipe.host_sync()      # the last image's download runs on the burst's own stream
 
+    # N > 1: a transport that hangs (it has never run with more than one rank before the driver's own run) must not hang the
+    # launcher: if the bursts before the timed region do not complete, this rank exits non-zero -- torch.distributed.run then
+    # ends the other ranks, and the plain command's parent (spawn_ranks) falls back to the in-process group
+    watchdog = None
+    if world > 1 or grp is not None:
+        import threading
+        hang_s = float(os.environ.get("MFSR_BENCH_HANG_S", "300"))
+
+        def _hung():
+            print(f"bench.py: rank {rank}: the bursts before the timed region did not complete within {hang_s:.0f} s "
+                  f"(transport {'local group' if grp is not None else dist_impl}): giving up", file=sys.stderr, flush=True)
+            os._exit(5)
+
+        watchdog = threading.Timer(hang_s, _hung)
+        watchdog.daemon = True
+        watchdog.start()
+    if os.environ.get("MFSR_BENCH_TEST_HANG") == "1" and rank == world - 1:      # (test hook: this rank never arrives)
+        time.sleep(3600)
     if world > 1 and not ctl_gloo:  # (torch mirror) bring torch's RCCL communicator up outside the timed region even with --warmup 0
         dist.all_reduce(torch.zeros(1, device=dev))
     for _ in range(args.warmup):
@@ -602,6 +620,8 @@ def main():
                 halo_note = f"raw halo {halo} rows from the measured vertical flow {v.value:.2f} px (default 64)"
                 step()
                 barrier()
+    if watchdog is not None:
+        watchdog.cancel()
     from multi_frame_super_resolution_amd import capi as _capi
     LIB = _capi.lib()
     # (local group: rank 0's burst context is the one whose warp+fuse launches are event-timed)

@@ -257,3 +257,26 @@ def test_bench_ranks_agree_on_the_in_process_fallback_when_rccl_does_not_come_up
     assert q.returncode == 0, q.stderr[-2000:]
     e = json.loads([l for l in q.stdout.splitlines() if l.strip().startswith("{")][0])
     assert d["out16_sha256_16"] == e["out16_sha256_16"] and e["out16_sha256_16"]
+
+
+def test_bench_rank_that_never_arrives_ends_the_run_instead_of_hanging_it():
+    """A transport that hangs must not hang the launcher: the bursts before the timed region run under a watchdog
+    (MFSR_BENCH_HANG_S, default 300 s).  Here rank 1 of a two-rank gloo rehearsal never arrives (MFSR_BENCH_TEST_HANG=1): both
+    ranks give up after the limit, the parent returns non-zero with the reason on stderr, and no line is printed."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(MFSR_DIST_BACKEND="gloo", MFSR_BENCH_TEST_HANG="1", MFSR_BENCH_HANG_S="20", MFSR_BENCH_NO_FALLBACK="1")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-impl", "rccl", "--steps", "1", "--warmup", "1",
+                        "--workload", "1080p5_gray_x2", "--no-cpu-baseline", "--no-e2e", "--no-isolated"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode != 0
+    assert "did not complete within 20 s" in p.stderr, p.stderr[-2000:]
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert time.time() - t0 < 300
