@@ -10,12 +10,15 @@ from multi_frame_super_resolution_amd.pipeline import default_config
 from multi_frame_super_resolution_amd.synth import make_burst
 from tests.burst_compare import run_hip
 
-W, H, N, s = 3840, 2160, 5, 2
+W, H, N, s = 3840, 2160, 16, 2      # the headline burst (bench.py: seed 1236)
 if len(sys.argv) > 1:
     W, H = (int(v) for v in sys.argv[1].split("x"))
+if len(sys.argv) > 2:
+    N = int(sys.argv[2])
 frames, _, _ = make_burst(W, H, N, scale=s, mono=False, seed=1236, device="cpu")
 cfg = default_config(W, H, N, s, False)
 h = run_hip(cfg, frames)
+tot = {}
 for k in range(N):
     if k == cfg.reference:
         continue
@@ -27,4 +30,10 @@ for k in range(N):
     for (cw, ch) in ((66, 2), (18, 3), (34, 2), (3, 2)):
         hh, ww = sat.shape
         a = sat[: hh // ch * ch, : ww // cw * cw].reshape(hh // ch, ch, ww // cw, cw)
-        print(f"    windows {cw}x{ch} all saturated: {a.all(axis=(1, 3)).mean():.4f}")
+        share = float(a.all(axis=(1, 3)).mean())
+        tot.setdefault((cw, ch), []).append(share)
+        print(f"    windows {cw}x{ch} all saturated: {share:.4f}")
+print("mean over the moved frames (the reference frame's mask is all 1: the share of a 16-frame burst's (wave, frame) pairs is (15 x this + 1) / 16):")
+for (cw, ch), v in tot.items():
+    m = float(np.mean(v))
+    print(f"    footprint {cw} x {ch} texels: {m:.4f} of the moved frames' windows saturated -> {(m * (N - 1) + 1) / N:.4f} of the burst's")
