@@ -28,6 +28,21 @@ def _pitch(a):
     return int(a.strides[0])
 
 
+BAND_ROWS = 256
+
+
+def map_row_bands(fn, rows, band_rows=None, threads=None):
+    """[fn(y0, y1) for consecutive row bands] on a thread pool (the HR arrays of a 4K x4 / 8K burst have 133 M pixels: whole-array
+    numpy expressions on them are single-threaded and allocate gigabytes of temporaries)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    band_rows = band_rows or BAND_ROWS
+    bands = [(y, min(y + band_rows, rows)) for y in range(0, rows, band_rows)]
+    threads = threads or min(16, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        return list(ex.map(lambda b: fn(*b), bands))
+
+
 def _dilate(m: np.ndarray, r: int) -> np.ndarray:
     """Binary dilation by a (2r+1)^2 box (numpy only)."""
     out = m.copy()
@@ -74,22 +89,32 @@ class FlipSet:
         self.o.dbgRobustnessShifts(flow, _pitch(flow), flow.shape[1], flow.shape[0], self.hw, self.hh, val, sh)
         return val, sh
 
-    def add_frame(self, flow_h, flow_o, mask_h, mask_o):
+    def add_frame(self, flow_h, flow_o, mask_h, mask_o, numpy_reference=False):
         """flow_*: [th, tw, 2] float32 (raw-pixel units, what the fuse and robustness kernels read);
-        mask_*: [hh, hw, 4] float32 (.w = M)."""
+        mask_*: [hh, hw, 4] float32 (.w = M).  numpy_reference: decision (1) with the four HR-sized numpy arrays per frame
+        this class started with (kept as the check of the C form, tests/test_flipset_cpu.py)."""
         flow_h = np.ascontiguousarray(flow_h, np.float32)
         flow_o = np.ascontiguousarray(flow_o, np.float32)
         self.frames += 1
         self.max_flow_diff = max(self.max_flow_diff, float(np.abs(flow_h - flow_o).max()))
         # (1)
-        vh, sh = self._fuse_shifts(flow_h)
-        vo, so = self._fuse_shifts(flow_o)
-        a1 = (sh != so).any(-1)                                    # roundings that really differ
-        f1 = a1 | ((vh != vo).any(-1) & (_near_tie(vh, self.tie_eps) | _near_tie(vo, self.tie_eps)))   # + the tie guard
-        self.n["fuse_round"] += int(f1.sum())
-        self.n["fuse_round_actual"] += int(a1.sum())
-        self.flips |= f1
-        self.flips_actual |= a1
+        if numpy_reference:
+            vh, sh = self._fuse_shifts(flow_h)
+            vo, so = self._fuse_shifts(flow_o)
+            a1 = (sh != so).any(-1)                                    # roundings that really differ
+            f1 = a1 | ((vh != vo).any(-1) & (_near_tie(vh, self.tie_eps) | _near_tie(vo, self.tie_eps)))   # + the tie guard
+            self.n["fuse_round"] += int(f1.sum())
+            self.n["fuse_round_actual"] += int(a1.sum())
+            self.flips |= f1
+            self.flips_actual |= a1
+        else:
+            # the same decision per HR pixel in one pass of oracle/diagnostics.c (OpenMP), written into the two sets in place
+            assert flow_h.shape == flow_o.shape and _pitch(flow_h) == _pitch(flow_o)
+            counts = np.zeros(2, np.int64)
+            self.o.dbgFuseFlips(flow_h, flow_o, _pitch(flow_h), flow_h.shape[1], flow_h.shape[0], self.W, self.H, self.s,
+                                float(self.tie_eps), self.flips.view(np.uint8), self.flips_actual.view(np.uint8), counts)
+            self.n["fuse_round"] += int(counts[0])
+            self.n["fuse_round_actual"] += int(counts[1])
         # (2) + (3), half resolution
         rvh, rsh = self._robust_shifts(flow_h)
         rvo, rso = self._robust_shifts(flow_o)
@@ -105,8 +130,15 @@ class FlipSet:
             if m.any():
                 # certainty site of HR pixel X, tap px: floor((X+px)/s)/2, px in [-2,2]  ->  half-res pixel x is read by
                 # X in [2s*x - 2, 2s*x + 2s + 1]
-                up = np.repeat(np.repeat(m, 2 * self.s, 0), 2 * self.s, 1)[:self.hrH, :self.hrW]
-                dst[:up.shape[0], :up.shape[1]] |= _dilate(up, 2)
+                ys, xs = np.nonzero(m)
+                if numpy_reference or ys.size > 50000:
+                    up = np.repeat(np.repeat(m, 2 * self.s, 0), 2 * self.s, 1)[:self.hrH, :self.hrW]
+                    dst[:up.shape[0], :up.shape[1]] |= _dilate(up, 2)
+                else:   # the usual case, a few hundred cells: their HR blocks directly
+                    b = 2 * self.s
+                    ly, lx = min(b * m.shape[0], self.hrH), min(b * m.shape[1], self.hrW)   # (the up-sampled mask's extent)
+                    for y, x in zip(ys.tolist(), xs.tolist()):
+                        dst[max(b * y - 2, 0):min(b * y + b + 2, ly), max(b * x - 2, 0):min(b * x + b + 2, lx)] = True
 
     def add_weights(self, tw_h, tw_o):
         """(4): the accumulated weights on either side of ApplyWeighting's threshold."""
@@ -117,26 +149,38 @@ class FlipSet:
         self.flips_actual |= f4
 
     def report(self, h_out, o_out, h16, o16):
-        """Error statistics inside / outside the flip set (8 bit: the CLI's output depth; 16 bit as the finer diagnostic)."""
-        d8 = np.abs(np.round(np.clip(h_out, 0, 1) * 255.0) - np.round(np.clip(o_out, 0, 1) * 255.0)).max(-1)
-        d16 = np.abs(h16.astype(np.int64) - o16.astype(np.int64)).max(-1)
+        """Error statistics inside / outside the flip set (8 bit: the CLI's output depth; 16 bit as the finer diagnostic).
+        Row bands on a thread pool (numpy releases the GIL): the same per-sample expressions, partial maxima / counts merged."""
         E = self.flips
-        inside, outside = E, ~E
         tot = float(E.size)
+
+        def band(y0, y1):
+            e = E[y0:y1]
+            d8 = np.abs(np.round(np.clip(h_out[y0:y1], 0, 1) * 255.0) - np.round(np.clip(o_out[y0:y1], 0, 1) * 255.0)).max(-1)
+            d16 = np.abs(h16[y0:y1].astype(np.int64) - o16[y0:y1].astype(np.int64)).max(-1)
+            i8, o8, i16, o16_ = d8[e], d8[~e], d16[e], d16[~e]
+            return dict(max8_inside=int(i8.max()) if i8.size else 0, max8_outside=int(o8.max()) if o8.size else 0,
+                        n_gt1_8bit_inside=int((i8 > 1).sum()), n_gt1_8bit_outside=int((o8 > 1).sum()),
+                        max16_inside=int(i16.max()) if i16.size else 0, max16_outside=int(o16_.max()) if o16_.size else 0,
+                        n16_out=int((o16_ > 1).sum()), n8=int((d8 > 1).sum()), n16=int((d16 > 1).sum()))
+
+        parts = map_row_bands(band, E.shape[0])
+        mx = lambda k: max(q[k] for q in parts)
+        sm = lambda k: sum(q[k] for q in parts)
         r = {
             "flip_fraction": float(E.sum()) / tot,
             "flip_fraction_no_guard": float(self.flips_actual.sum()) / tot,
             "tie_eps": self.tie_eps,
             "flips_by_cause_per_frame": {k: v / max(self.frames, 1) / tot for k, v in self.n.items()},
             "max_flow_diff_px": self.max_flow_diff,
-            "max8_inside": int(d8[inside].max()) if inside.any() else 0,
-            "max8_outside": int(d8[outside].max()) if outside.any() else 0,
-            "n_gt1_8bit_inside": int((d8[inside] > 1).sum()),
-            "n_gt1_8bit_outside": int((d8[outside] > 1).sum()),
-            "max16_inside": int(d16[inside].max()) if inside.any() else 0,
-            "max16_outside": int(d16[outside].max()) if outside.any() else 0,
-            "frac_gt1_16bit_outside": float((d16[outside] > 1).sum()) / tot,
-            "frac_gt1_8bit": float((d8 > 1).sum()) / tot,
-            "frac_gt1_16bit": float((d16 > 1).sum()) / tot,
+            "max8_inside": mx("max8_inside"),
+            "max8_outside": mx("max8_outside"),
+            "n_gt1_8bit_inside": sm("n_gt1_8bit_inside"),
+            "n_gt1_8bit_outside": sm("n_gt1_8bit_outside"),
+            "max16_inside": mx("max16_inside"),
+            "max16_outside": mx("max16_outside"),
+            "frac_gt1_16bit_outside": float(sm("n16_out")) / tot,
+            "frac_gt1_8bit": float(sm("n8")) / tot,
+            "frac_gt1_16bit": float(sm("n16")) / tot,
         }
         return r

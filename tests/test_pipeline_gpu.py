@@ -376,48 +376,21 @@ def _flow_locks(h, shifts, k, fs):
     np.testing.assert_allclose(np.median(c.reshape(-1, 2), 0), -shifts[k].cpu().numpy(), atol=0.15)
 
 
-def test_config1_1080p_gray_x2_vs_oracle():
-    """BASELINE configs[1] frame size (1920x1080 gray, x2) on a 2-frame sample against the oracle."""
-    from multi_frame_super_resolution_amd.synth import make_burst
-    W, H, N = 1920, 1080, 2
-    frames, shifts, _ = make_burst(W, H, N, scale=2, mono=True, seed=1234 + 1)
-    cfg = _cfg(W, H, N, 2, True, 1)
-    h = run_hip(cfg, frames)
-    o = run_oracle(cfg, frames)
-    np.testing.assert_allclose(h["tracking"], o["tracking"], atol=1e-6)
-    _flow_locks(h, shifts, 1, 1)
-    _flow_differences_are_localised(cfg, h, o, "configs[1]")
-    assert_parity(classify(cfg, h, o), "configs[1] 1080p gray x2, 2-frame sample")
-
-
 def test_config1_as_stated_5_frames_1080p_gray_vs_oracle():
     """BASELINE configs[1] AS STATED: the 5-frame 1920x1080 grayscale burst, x2 (monochrome tile kernel, groups of two frames,
-    a last group of one) against the oracle, every frame in the classification."""
+    a last group of one) against the oracle, every frame in the classification.  (The 2-frame and 4-frame SAMPLES of configs[1]
+    and configs[2] that rounds 1-3 tested are subsets of this test and of the 16-frame one below: removed in round 4.)"""
     from multi_frame_super_resolution_amd.synth import make_burst
     W, H, N = 1920, 1080, 5
     frames, shifts, _ = make_burst(W, H, N, scale=2, mono=True, seed=1234 + 1)
     cfg = _cfg(W, H, N, 2, True, 1)
     h = run_hip(cfg, frames)
     o = run_oracle(cfg, frames)
+    np.testing.assert_allclose(h["tracking"], o["tracking"], atol=1e-6)
     for k in range(1, N):
         _flow_locks(h, shifts, k, 1)
     _flow_differences_are_localised(cfg, h, o, "configs[1] x 5")
     assert_parity(classify(cfg, h, o), "configs[1] 1080p gray x2, the full 5-frame burst")
-
-
-def test_config2_4k_rggb_x2_sample_vs_oracle():
-    """BASELINE configs[2] frame size (3840x2160 RGGB, x2), 4 moved-and-noisy frames, against the oracle: the
-    asserted version of bench.py's cpu_baseline.parity_on_sample."""
-    from multi_frame_super_resolution_amd.synth import make_burst
-    W, H, N = 3840, 2160, 4
-    frames, shifts, _ = make_burst(W, H, N, scale=2, mono=False, seed=1234 + 2)
-    cfg = _cfg(W, H, N, 2, False, 1)
-    h = run_hip(cfg, frames)
-    o = run_oracle(cfg, frames)
-    for k in range(1, N):
-        _flow_locks(h, shifts, k, 2)
-    _flow_differences_are_localised(cfg, h, o, "configs[2]")
-    assert_parity(classify(cfg, h, o), "configs[2] 4K RGGB x2, 4-frame sample")
 
 
 def test_config2_full_burst_16_frames_4k_vs_oracle():
