@@ -8,11 +8,12 @@
 // :262-264): t is in [-pi/2, pi/2], so cos t >= 0 and sin t has the sign of y; the half-angle
 // identities are taken in their cancellation-free form.  Agrees with cosf/sinf(0.5f * atan2f()) to a
 // few ulp; (0, 0) gives t = 0 like atan2f, NaN propagates.
-__device__ __forceinline__ void lk_half_angle(float y, float x, float& ct, float& st)
+__device__ __forceinline__ void lk_half_angle(float y, float x, float& ct, float& st, float* rOut = nullptr)
 {
     // v_sqrt_f32 / v_rcp_f32 / v_rsq_f32 (1 ulp) instead of the IEEE-exact expansions: this routine is
     // a few-ulp replacement of libm calls to begin with
     const float r = __builtin_amdgcn_sqrtf(x * x + y * y);
+    if (rOut) *rOut = r;
     if (r == 0.0f) {
         ct = 1.0f;
         st = 0.0f;
@@ -35,13 +36,15 @@ __device__ __forceinline__ bool lk_pinv(float a, float b, float d, float minDet,
 {
     const float c = b;  // matMul[2] = matMul[1] (:234)
     float ct, st;
-    lk_half_angle(2.0f * a * c + 2.0f * b * d, a * a + b * b - c * c - d * d, ct, st);  // theta = atan2(..)/2 (:236-238)
+    float S2;
+    lk_half_angle(2.0f * a * c + 2.0f * b * d, a * a + b * b - c * c - d * d, ct, st, &S2);  // theta = atan2(..)/2 (:236-238)
     const float UT0 = ct, UT2 = -st, UT1 = st, UT3 = ct;
     const float S1 = a * a + b * b + c * c + d * d;
+    // S2 (:244-245) = sqrt((a a + b b - c c - d d)^2 + 4 (a c + b d)^2) is the modulus r the half-angle routine has just taken
+    // of (x, y) = (a a + b b - c c - d d, 2 a c + 2 b d): y = 2 (a c + b d) exactly (a scaling by two commutes with the
+    // roundings), so y y = 4 (a c + b d)^2 bit for bit -- the same number, one square root instead of two.
     // v_sqrt_f32 / v_rcp_f32 (1 ulp) for sqrtf and 1/x: sigma2 comes out of a cancellation (S1 - S2)
     // whose error dwarfs an ulp, so the IEEE-exact expansions buy nothing here
-    const float S2 = __builtin_amdgcn_sqrtf((a * a + b * b - c * c - d * d) * (a * a + b * b - c * c - d * d) +
-                                            4 * (a * c + b * d) * (a * c + b * d));
     float sigma1 = __builtin_amdgcn_sqrtf((S1 + S2) * 0.5f);
     float sigma2 = __builtin_amdgcn_sqrtf((S1 - S2) * 0.5f);
     const float smin = fminf(sigma1, sigma1);  // (sic) :255
