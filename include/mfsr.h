@@ -623,6 +623,12 @@ int mfsr_checkFlowBound(const mfsr_float2* flow, int pitch, int width, int rows,
  * like their bit patterns; NaN is skipped): the measured vertical flow a multi-GPU caller sizes the raw-row halo of the
  * next bursts from (mfsr_dist_measured_flow) */
 int mfsr_maxAbsFlowY(const mfsr_float2* flow, int pitch, int width, int rows, int* maxBits, mfsr_stream_t stream);
+/* Host-only diagnostic (no device call): 1 if the kernels divide by `d` -- an image dimension, the divisor of the reference's
+ * normalised texture coordinates (opticalFlow.cu:38-39, :88; RobustnessModell.cu:59-77) -- with the reciprocal sequence
+ * q = x (1/d), q' = fma(fma(-d, q, x), 1/d, q), which this library takes only after checking on the host, over all 2^23
+ * significands, that it IS the correctly rounded x / d for every x; 0 if they keep the division (check failed, d outside
+ * (0, 2^24), or MFSR_EXACT_DIV=0). */
+int mfsr_exactDivisionOk(float d);
 
 /* ---- frame streams (BASELINE configs[4]): a sliding window of 2*radius+1 frames around every
  * frame, the reference's setTemporalAreaRadius(1) (finalProject/Project/multi_frame_sr.cpp:182).  Output t fuses frames

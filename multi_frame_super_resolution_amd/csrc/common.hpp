@@ -54,6 +54,29 @@ struct MfsrBatch {
     const void* p[MFSR_BATCH_MAX][6];
 };
 int mfsr_cfa_packed();  // defined in debayer.hip (process-wide state)
+// x / d for a divisor that is the same for a whole launch (an image dimension): q = x r, q' = fma(fma(-d, q, x), r, q) with
+// r = RN(1 / d) -- two multiply-adds after the product instead of the ~10 instructions of the IEEE division expansion.  For a
+// given d the sequence either is the correctly rounded quotient for EVERY x or it is not (scaling x by a power of two
+// commutes with every rounding involved), so the host checks it once per divisor over all 2^23 significands of one binade
+// (mfsr_exact_div in glue.hip: ~15 ms, cached) and the kernels take the sequence only when that check passed (ok), else the
+// division: bit-identical to `x / d` by construction.  (Every image dimension tried passes; the check is the proof, not the
+// assumption.)  Infinite and NaN quotients (an infinite flow) are passed through as the division gives them.
+// MFSR_EXACT_DIV=0: always the division (A/B).
+struct MfsrExactDiv {
+    float d, r;
+    int ok;
+};
+MfsrExactDiv mfsr_exact_div(float d);  // host; glue.hip
+__device__ __forceinline__ float mfsr_div(float x, const MfsrExactDiv& e)
+{
+    if (e.ok) {  // uniform
+        const float q = x * e.r;
+        const float q2 = __builtin_fmaf(__builtin_fmaf(-e.d, q, x), e.r, q);
+        return fabsf(q) < __builtin_inff() ? q2 : q;
+    }
+    return x / e.d;
+}
+
 __device__ __forceinline__ int cfa_at(int packed, int y, int x) { return (packed >> ((((y & 1) << 1) | (x & 1)) << 3)) & 0xff; }
 
 // ---- row addressing with byte pitches ----------------------------------------

@@ -694,3 +694,36 @@ extern "C" int mfsr_checkFlowBound(const mfsr_float2* flow, int pitch, int width
     hipLaunchKernelGGL(k_checkFlowBound, grid, block, 0, mfsr_s(stream), (const float2*)flow, pitch, width, rows, bound, flag);
     return mfsr_launch_status("checkFlowBound");
 }
+
+// ---- mfsr_exact_div (common.hpp) -----------------------------------------------------------------------------------------
+#include <mutex>
+MfsrExactDiv mfsr_exact_div(float d)
+{
+    static std::mutex mu;
+    static MfsrExactDiv cache[32];
+    static int nCache = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < nCache; i++)
+        if (cache[i].d == d) return cache[i];
+    MfsrExactDiv e{d, 1.0f / d, 0};
+    static const bool off = [] {
+        const char* v = getenv("MFSR_EXACT_DIV");
+        return v && v[0] == '0';
+    }();
+    if (!off && d > 0.0f && d < 16777216.0f) {
+        bool ok = true;
+        for (uint32_t m = 0; m < (1u << 23) && ok; m++) {
+            const uint32_t bits = (127u << 23) | m;
+            float x;
+            memcpy(&x, &bits, 4);
+            const float q = x * e.r;
+            // (host arithmetic: -ffp-contract=off, fmaf is the correctly rounded one)
+            ok = fmaf(fmaf(-d, q, x), e.r, q) == x / d;
+        }
+        e.ok = ok ? 1 : 0;
+    }
+    if (nCache < 32) cache[nCache++] = e;
+    return e;
+}
+
+extern "C" int mfsr_exactDivisionOk(float d) { return mfsr_exact_div(d).ok; }

@@ -54,11 +54,12 @@ __device__ __forceinline__ int lk_mirror_index(int i, int n)
 // clamped, so the fetch is four plain loads with the very same arithmetic as tex1<ADDR_MIRROR>; the few other samples
 // are redone with the full addressing (wave-uniform branch: only waves that touch the image border pay for it).
 __device__ __forceinline__ void lk_warp_sample(const float* __restrict__ refImg, const float* __restrict__ movedImg, int pitchImg,
-                                               int width, int height, int gx, int gy, float2 f, float& wv, float& rv)
+                                               int width, int height, int gx, int gy, float2 f, float& wv, float& rv,
+                                               const MfsrExactDiv* dW = nullptr, const MfsrExactDiv* dH = nullptr)
 {
     rv = row_ptr(refImg, pitchImg, gy)[gx];
-    const float u = ((float)gx + 0.5f + f.x) / (float)width;   // opticalFlow.cu:38-39
-    const float v = ((float)gy + 0.5f + f.y) / (float)height;
+    const float u = dW ? mfsr_div((float)gx + 0.5f + f.x, *dW) : ((float)gx + 0.5f + f.x) / (float)width;   // opticalFlow.cu:38-39
+    const float v = dH ? mfsr_div((float)gy + 0.5f + f.y, *dH) : ((float)gy + 0.5f + f.y) / (float)height;
     const float xB = u * (float)width - 0.5f, yB = v * (float)height - 0.5f;
     const float fx = floorf(xB), fy = floorf(yB);
     const int ix = f2i(fx), iy = f2i(fy);
@@ -374,7 +375,7 @@ __global__ void __launch_bounds__(256)
     k_flowFieldWarped(float2* __restrict__ outImg, mfsr_tex2d texShift, int imgWidth, int imgHeight, int imgPitch, float2 baseShift,
                       float baseRotation, const mfsr_prealign* __restrict__ base, const float* __restrict__ refImg,
                       const float* __restrict__ movedImg, int pitchImg, float* __restrict__ sumOut, float* __restrict__ diffOut,
-                      int pitchSD, MfsrBatch bt)
+                      int pitchSD, MfsrBatch bt, MfsrExactDiv dW, MfsrExactDiv dH)
 {
     if (gridDim.z > 1) {
         outImg = (float2*)bt.p[blockIdx.z][0];
@@ -410,12 +411,12 @@ __global__ void __launch_bounds__(256)
     shift.x += cf * patchCenterX - sf * patchCenterY - patchCenterX;
     shift.y += sf * patchCenterX + cf * patchCenterY - patchCenterY;
     const float2 shiftPatch =
-        tex2<ADDR_CLAMP>(texShift, ((float)pxX + 0.5f) / (float)imgWidth, ((float)pxY + 0.5f) / (float)imgHeight);
+        tex2<ADDR_CLAMP>(texShift, mfsr_div((float)pxX + 0.5f, dW), mfsr_div((float)pxY + 0.5f, dH));   // / imgWidth, / imgHeight
     shift.x += shiftPatch.x;
     shift.y += shiftPatch.y;
     row_ptr(outImg, imgPitch, pxY)[pxX] = shift;
     float wv, rv;
-    lk_warp_sample(refImg, movedImg, pitchImg, imgWidth, imgHeight, pxX, pxY, shift, wv, rv);
+    lk_warp_sample(refImg, movedImg, pitchImg, imgWidth, imgHeight, pxX, pxY, shift, wv, rv, &dW, &dH);
     row_ptr(sumOut, pitchSD, pxY)[pxX] = wv + rv;
     row_ptr(diffOut, pitchSD, pxY)[pxX] = wv - rv;
 }
@@ -447,13 +448,14 @@ static int flow_field_warped_impl(int n, const mfsr_flowfield_frame* f, int tile
         bt.p[i][5] = f[i].diffOut;
     }
     dim3 block(64, 4), grid(mfsr_cdiv(imgWidth, 64), mfsr_cdiv(imgHeight, 4), n);
+    const MfsrExactDiv dW = mfsr_exact_div((float)imgWidth), dH = mfsr_exact_div((float)imgHeight);
     if (f[0].base)
         hipLaunchKernelGGL(k_flowFieldWarped<true>, grid, block, 0, mfsr_s(stream), (float2*)f[0].outImg, tex, imgWidth, imgHeight, imgPitch,
-                           make_float2(0.0f, 0.0f), 0.0f, f[0].base, refImg, f[0].movedImg, pitchImg, f[0].sumOut, f[0].diffOut, pitchSD, bt);
+                           make_float2(0.0f, 0.0f), 0.0f, f[0].base, refImg, f[0].movedImg, pitchImg, f[0].sumOut, f[0].diffOut, pitchSD, bt, dW, dH);
     else
         hipLaunchKernelGGL(k_flowFieldWarped<false>, grid, block, 0, mfsr_s(stream), (float2*)f[0].outImg, tex, imgWidth, imgHeight, imgPitch,
                            make_float2(baseShift.x, baseShift.y), baseRotation, f[0].base, refImg, f[0].movedImg, pitchImg, f[0].sumOut,
-                           f[0].diffOut, pitchSD, bt);
+                           f[0].diffOut, pitchSD, bt, dW, dH);
     return mfsr_launch_status("CreateFlowFieldWarped");
 }
 
@@ -523,10 +525,10 @@ struct LkGather {
     bool interior;
 };
 __device__ __forceinline__ void lk_warp_issue(const float* __restrict__ movedImg, int pitchImg, int width, int height, int gx, int gy,
-                                              float2 f, float rv, LkGather& g)
+                                              float2 f, float rv, LkGather& g, const MfsrExactDiv& dW, const MfsrExactDiv& dH)
 {
-    const float u = ((float)gx + 0.5f + f.x) / (float)width;   // opticalFlow.cu:38-39
-    const float v = ((float)gy + 0.5f + f.y) / (float)height;
+    const float u = mfsr_div((float)gx + 0.5f + f.x, dW);   // opticalFlow.cu:38-39: / (float)width
+    const float v = mfsr_div((float)gy + 0.5f + f.y, dH);   //                        / (float)height
     const float xB = u * (float)width - 0.5f, yB = v * (float)height - 0.5f;
     const float fx = floorf(xB), fy = floorf(yB);
     const int ix = f2i(fx), iy = f2i(fy);
@@ -557,7 +559,7 @@ __device__ __forceinline__ float lk_warp_finish(const float* __restrict__ movedI
 template <int HT>
 __global__ void __launch_bounds__(64)
     k_lkSweep(LkSweepBatch batch, const float* __restrict__ refImg, int pitchShift, int pitchImg, int pitchSD, int width, int height,
-              float minDet, float outScale, int bandRows, int strips, int bands, int perXcd, int nFramesLaunch)
+              float minDet, float outScale, int bandRows, int strips, int bands, int perXcd, int nFramesLaunch, MfsrExactDiv dW, MfsrExactDiv dH)
 {
     constexpr int h = HT, HALO = HT + 2, WIN = 2 * HT + 1, VW = 64 - 2 * HALO;
     // XCD-aware order (perXcd > 0): workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  A band re-reads
@@ -675,7 +677,7 @@ __global__ void __launch_bounds__(64)
             }
             if (F.sumOut) {   // wave-uniform
                 finish_pending();   // the previous row's gather: issued one row ago
-                lk_warp_issue(F.moved, pitchImg, width, height, colOutC, y, shift, rvOwn, pend);
+                lk_warp_issue(F.moved, pitchImg, width, height, colOutC, y, shift, rvOwn, pend, dW, dH);
                 pendY = y;
             }
             shift.x *= outScale;
@@ -726,10 +728,11 @@ extern "C" int mfsr_lucasKanadeSweepBatch(int nFrames, const mfsr_lk_frame* fram
     const int perXcd = xcdRemap ? mfsr_cdiv(total, 8) : 0;
     // (remapped: a 1-D grid of 8 * perXcd workgroups whose .z still carries the frame count for the kernel's bound check)
     dim3 grid = perXcd ? dim3(8 * perXcd, 1, 1) : dim3(strips, bands, nFrames), block(64);
+    const MfsrExactDiv dW = mfsr_exact_div((float)width), dH = mfsr_exact_div((float)height);
 #define LKS_CASE(HT)                                                                                                          \
     case HT:                                                                                                                  \
         hipLaunchKernelGGL(k_lkSweep<HT>, grid, block, 0, mfsr_s(stream), b, refImg, pitchShift, pitchImg, pitchSD, width,    \
-                           height, minDet, outScale, band, strips, bands, perXcd, nFrames);                                   \
+                           height, minDet, outScale, band, strips, bands, perXcd, nFrames, dW, dH);                           \
         break;
     switch (h) {
         LKS_CASE(1)

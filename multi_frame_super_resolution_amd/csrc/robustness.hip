@@ -142,7 +142,7 @@ template <bool ALIGNED>
 __global__ void __launch_bounds__(RB_TX* RB_TY)
     k_robustnessFused(const pix3* __restrict__ rawImgRef, const pix3* __restrict__ rawImgMoved, float4* __restrict__ robustnessMask,
                       mfsr_tex2d texUV, int imgWidth, int imgHeight, int imgPitch, int maskPitch, float alpha, float beta,
-                      float thresholdM, MfsrBatch bt)
+                      float thresholdM, MfsrBatch bt, MfsrExactDiv dW, MfsrExactDiv dH)
 {
     if (gridDim.z > 1) {
         rawImgMoved = (const pix3*)bt.p[blockIdx.z][0];
@@ -156,13 +156,13 @@ __global__ void __launch_bounds__(RB_TX* RB_TY)
     // this pixel's flow first: its fetch and the moved-image gather that depends on it are then in flight while the
     // reference patch is staged (three dependent round trips become two)
     const int pxXe = min(x0 + lx, imgWidth - 1), pxYe = min(y0 + ly, imgHeight - 1);
-    const float2 shiftfE =
-        tex2<ADDR_CLAMP>(texUV, ((float)pxXe + 0.5f) / (float)imgWidth, ((float)pxYe + 0.5f) / (float)imgHeight);
+    // (/ imgWidth, / imgHeight: mfsr_div, common.hpp)
+    const float2 shiftfE = tex2<ADDR_CLAMP>(texUV, mfsr_div((float)pxXe + 0.5f, dW), mfsr_div((float)pxYe + 0.5f, dH));
     float2 sE;
     if (ALIGNED) {
         sE = row_ptr((const float2*)texUV.ptr, texUV.pitch, min(pxYe + 2, imgHeight - 1))[min(pxXe + 2, imgWidth - 1)];
     } else {
-        sE = tex2<ADDR_CLAMP>(texUV, ((float)pxXe + (float)2 + 0.5f) / (float)imgWidth, ((float)pxYe + (float)2 + 0.5f) / (float)imgHeight);
+        sE = tex2<ADDR_CLAMP>(texUV, mfsr_div((float)pxXe + (float)2 + 0.5f, dW), mfsr_div((float)pxYe + (float)2 + 0.5f, dH));
     }
 #endif
     for (int t = ly * RB_TX + lx; t < (RB_TY + 2) * (RB_TX + 2); t += RB_TX * RB_TY) {
@@ -296,12 +296,13 @@ extern "C" int mfsr_robustnessMaskFused(const mfsr_float3* rawImgRef, const mfsr
     MfsrBatch bt;
     memset(&bt, 0, sizeof(bt));
     dim3 block(RB_TX, RB_TY), grid(mfsr_cdiv(imgWidth, RB_TX), mfsr_cdiv(imgHeight, RB_TY));
+    const MfsrExactDiv dW = mfsr_exact_div((float)imgWidth), dH = mfsr_exact_div((float)imgHeight);
     if (texUV.width == imgWidth && texUV.height == imgHeight)
         hipLaunchKernelGGL(k_robustnessFused<true>, grid, block, 0, mfsr_s(stream), (const pix3*)rawImgRef, (const pix3*)rawImgMoved,
-                           (float4*)robustnessMask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM, bt);
+                           (float4*)robustnessMask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM, bt, dW, dH);
     else
         hipLaunchKernelGGL(k_robustnessFused<false>, grid, block, 0, mfsr_s(stream), (const pix3*)rawImgRef, (const pix3*)rawImgMoved,
-                           (float4*)robustnessMask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM, bt);
+                           (float4*)robustnessMask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM, bt, dW, dH);
     return mfsr_launch_status("robustnessMaskFused");
 }
 
@@ -330,12 +331,13 @@ extern "C" int mfsr_robustnessMaskFusedBatch(int nFrames, const mfsr_robustness_
         bt.p[i][2] = frames[i].flow;
     }
     dim3 block(RB_TX, RB_TY), grid(mfsr_cdiv(imgWidth, RB_TX), mfsr_cdiv(imgHeight, RB_TY), nFrames);
+    const MfsrExactDiv dW = mfsr_exact_div((float)imgWidth), dH = mfsr_exact_div((float)imgHeight);
     if (flowWidth == imgWidth && flowHeight == imgHeight)
         hipLaunchKernelGGL(k_robustnessFused<true>, grid, block, 0, mfsr_s(stream), (const pix3*)rawImgRef, (const pix3*)frames[0].movedHalf,
-                           (float4*)frames[0].mask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM, bt);
+                           (float4*)frames[0].mask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM, bt, dW, dH);
     else
         hipLaunchKernelGGL(k_robustnessFused<false>, grid, block, 0, mfsr_s(stream), (const pix3*)rawImgRef, (const pix3*)frames[0].movedHalf,
-                           (float4*)frames[0].mask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM, bt);
+                           (float4*)frames[0].mask, texUV, imgWidth, imgHeight, imgPitch, maskPitch, alpha, beta, thresholdM, bt, dW, dH);
     return mfsr_launch_status("robustnessMaskFusedBatch");
 }
 
