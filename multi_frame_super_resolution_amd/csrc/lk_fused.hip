@@ -49,6 +49,15 @@ __device__ __forceinline__ int lk_mirror_index(int i, int n)
     return i >= n ? 2 * n - 1 - i : i;
 }
 
+// base[y][x] for images of less than 4 GB: the byte offset y * pitch + 4 x in 32 bits, added to the (wave-uniform) base
+// pointer by the load's own address mode -- instead of a 64-bit multiply-add per row pointer and a 64-bit add per element
+// (8 to 9 VALU instructions per row step of the sweep).  The launcher checks pitch * height < 2^32.
+template <typename T>
+__device__ __forceinline__ T* lk_at(T* base, int pitch, int y, int x)
+{
+    return (T*)((char*)base + (uint32_t)((uint32_t)y * (uint32_t)pitch + (uint32_t)x * (uint32_t)sizeof(T)));
+}
+
 // warped moved image and reference at pixel (gx, gy) (inside the image) under flow f: opticalFlow.cu:28-44.
 // Interior samples (0 <= u,v < 1, both texel pairs inside the image): mirror_coord is the identity and no index is
 // clamped, so the fetch is four plain loads with the very same arithmetic as tex1<ADDR_MIRROR>; the few other samples
@@ -57,7 +66,7 @@ __device__ __forceinline__ void lk_warp_sample(const float* __restrict__ refImg,
                                                int width, int height, int gx, int gy, float2 f, float& wv, float& rv,
                                                const MfsrExactDiv* dW = nullptr, const MfsrExactDiv* dH = nullptr)
 {
-    rv = row_ptr(refImg, pitchImg, gy)[gx];
+    rv = *lk_at(refImg, pitchImg, gy, gx);
     const float u = dW ? mfsr_div((float)gx + 0.5f + f.x, *dW) : ((float)gx + 0.5f + f.x) / (float)width;   // opticalFlow.cu:38-39
     const float v = dH ? mfsr_div((float)gy + 0.5f + f.y, *dH) : ((float)gy + 0.5f + f.y) / (float)height;
     const float xB = u * (float)width - 0.5f, yB = v * (float)height - 0.5f;
@@ -66,8 +75,8 @@ __device__ __forceinline__ void lk_warp_sample(const float* __restrict__ refImg,
     const bool interior = u >= 0.0f && u < 1.0f && v >= 0.0f && v < 1.0f && (uint32_t)ix <= (uint32_t)(width - 2) &&
                           (uint32_t)iy <= (uint32_t)(height - 2);
     const int ixc = clampi(ix, 0, width - 2), iyc = clampi(iy, 0, height - 2);
-    const float* r0 = row_ptr(movedImg, pitchImg, iyc) + ixc;
-    const float* r1 = row_ptr(movedImg, pitchImg, iyc + 1) + ixc;
+    const float* r0 = lk_at(movedImg, pitchImg, iyc, ixc);
+    const float* r1 = lk_at(movedImg, pitchImg, iyc + 1, ixc);
     wv = lerp4(r0[0], r0[1], r1[0], r1[1], xB - fx, yB - fy);
     if (__ballot(!interior) != 0) {
         mfsr_tex2d texMoved;
@@ -284,6 +293,7 @@ static int lk_iteration_impl(const mfsr_float2* shiftsIn, mfsr_float2* shiftsOut
     MFSR_REQUIRE((long long)pitchImg >= 4LL * width && (pitchImg & 3) == 0);
     MFSR_REQUIRE((long long)pitchShift >= 8LL * width && (pitchShift & 7) == 0 && ((uintptr_t)shiftsIn & 7) == 0 &&
                  ((uintptr_t)shiftsOut & 7) == 0);
+    if ((long long)pitchImg * height >= (1LL << 32)) return MFSR_E_UNSUPPORTED;  // (lk_warp_sample: 32-bit byte offsets)
     const int h = halfWindowSize;
     // TX is a template parameter of the kernel: 48 only for the half-window sizes that have a <h,48>
     // instantiation below (1..7); every other size runs the generic <0,32> kernel
@@ -414,11 +424,11 @@ __global__ void __launch_bounds__(256)
         tex2<ADDR_CLAMP>(texShift, mfsr_div((float)pxX + 0.5f, dW), mfsr_div((float)pxY + 0.5f, dH));   // / imgWidth, / imgHeight
     shift.x += shiftPatch.x;
     shift.y += shiftPatch.y;
-    row_ptr(outImg, imgPitch, pxY)[pxX] = shift;
+    *lk_at(outImg, imgPitch, pxY, pxX) = shift;
     float wv, rv;
     lk_warp_sample(refImg, movedImg, pitchImg, imgWidth, imgHeight, pxX, pxY, shift, wv, rv, &dW, &dH);
-    row_ptr(sumOut, pitchSD, pxY)[pxX] = wv + rv;
-    row_ptr(diffOut, pitchSD, pxY)[pxX] = wv - rv;
+    *lk_at(sumOut, pitchSD, pxY, pxX) = wv + rv;
+    *lk_at(diffOut, pitchSD, pxY, pxX) = wv - rv;
 }
 
 static int flow_field_warped_impl(int n, const mfsr_flowfield_frame* f, int tilePitch, int tileW, int tileH, int imgWidth, int imgHeight,
@@ -428,6 +438,10 @@ static int flow_field_warped_impl(int n, const mfsr_flowfield_frame* f, int tile
     MFSR_REQUIRE(f && n >= 1 && n <= MFSR_BATCH_MAX && refImg && imgWidth >= 2 && imgHeight >= 2);
     MFSR_REQUIRE((long long)imgPitch >= 8LL * imgWidth && (imgPitch & 7) == 0);
     MFSR_REQUIRE((long long)pitchImg >= 4LL * imgWidth && (pitchImg & 3) == 0 && (long long)pitchSD >= 4LL * imgWidth && (pitchSD & 3) == 0);
+    // (32-bit byte offsets inside every image, lk_at: images of 4 GB and more are not this kernel's)
+    if ((long long)imgPitch * imgHeight >= (1LL << 32) || (long long)pitchImg * imgHeight >= (1LL << 32) ||
+        (long long)pitchSD * imgHeight >= (1LL << 32))
+        return MFSR_E_UNSUPPORTED;
     mfsr_tex2d tex;
     tex.ptr = f[0].tileShifts;
     tex.pitch = tilePitch;
@@ -520,41 +534,57 @@ __device__ __forceinline__ float lk_wshl1(float v)  // lane l <- lane l+1 (lane 
 
 // the warp of lk_warp_sample in two phases, so that the gather a pixel issues after its flow update is consumed one row
 // later (the wave works on the next row meanwhile): same address arithmetic, same blend, same bits
+// Register diet of k_lkSweep (round 4; all bit-identical, profiles/r04_lk_regs_ab.txt; h = 3): 32-bit offsets (lk_at) 95 -> 85
+// VGPRs and -3.6 % instructions: 110.3 -> 107 us per 4-frame launch; the border fetch at issue time (no coordinates / flag in
+// the pending gather) and the difference image loaded two steps before its use instead of four (LK_DIFF_LATE): 79 VGPRs = six
+// waves per SIMD: 106 us.  LK_RV_REREAD=1 (the reference pixel re-read at the finish instead of held in a register: 76 VGPRs)
+// puts a load in front of the two stores of every row: 120 us -- off.
+#ifndef LK_RV_REREAD
+#define LK_RV_REREAD 0
+#endif
+#ifndef LK_DIFF_LATE
+#define LK_DIFF_LATE 1
+#endif
+// What a pending warp keeps across a row step: the four texels on their way, the blend weights and the reference pixel -- seven
+// registers (LkGather + rv).  A sample the plain fetch does not cover (outside the unit square or on the last texel row / column: waves at the
+// image border only) is fetched with the full MIRROR addressing right here, under a wave-uniform branch, and parked as four
+// equal texels with zero weights: lerp4 of those returns it bit for bit ((t + 0) + 0 + 0), so the finish needs neither the
+// coordinates nor an "interior" flag.
 struct LkGather {
-    float t00, t10, t01, t11, a, b, rv, u, v;
-    bool interior;
+    float t00, t10, t01, t11, a, b;
+#if !LK_RV_REREAD
+    float rv;
+#endif
 };
 __device__ __forceinline__ void lk_warp_issue(const float* __restrict__ movedImg, int pitchImg, int width, int height, int gx, int gy,
-                                              float2 f, float rv, LkGather& g, const MfsrExactDiv& dW, const MfsrExactDiv& dH)
+                                              float2 f, bool wanted, LkGather& g, const MfsrExactDiv& dW, const MfsrExactDiv& dH)
 {
     const float u = mfsr_div((float)gx + 0.5f + f.x, dW);   // opticalFlow.cu:38-39: / (float)width
     const float v = mfsr_div((float)gy + 0.5f + f.y, dH);   //                        / (float)height
     const float xB = u * (float)width - 0.5f, yB = v * (float)height - 0.5f;
     const float fx = floorf(xB), fy = floorf(yB);
     const int ix = f2i(fx), iy = f2i(fy);
-    g.interior = u >= 0.0f && u < 1.0f && v >= 0.0f && v < 1.0f && (uint32_t)ix <= (uint32_t)(width - 2) &&
-                 (uint32_t)iy <= (uint32_t)(height - 2);
+    const bool interior = u >= 0.0f && u < 1.0f && v >= 0.0f && v < 1.0f && (uint32_t)ix <= (uint32_t)(width - 2) &&
+                          (uint32_t)iy <= (uint32_t)(height - 2);
     const int ixc = clampi(ix, 0, width - 2), iyc = clampi(iy, 0, height - 2);
-    const float* r0 = row_ptr(movedImg, pitchImg, iyc) + ixc;
-    const float* r1 = row_ptr(movedImg, pitchImg, iyc + 1) + ixc;
+    const float* r0 = lk_at(movedImg, pitchImg, iyc, ixc);
+    const float* r1 = lk_at(movedImg, pitchImg, iyc + 1, ixc);
     g.t00 = r0[0], g.t10 = r0[1], g.t01 = r1[0], g.t11 = r1[1];
     g.a = xB - fx, g.b = yB - fy;
-    g.rv = rv, g.u = u, g.v = v;
-}
-__device__ __forceinline__ float lk_warp_finish(const float* __restrict__ movedImg, int pitchImg, int width, int height, const LkGather& g)
-{
-    float wv = lerp4(g.t00, g.t10, g.t01, g.t11, g.a, g.b);
-    if (__ballot(!g.interior) != 0) {
+    if (__ballot(!interior && wanted) != 0) {   // (lanes whose result is not stored do not send the wave here)
         mfsr_tex2d texMoved;
         texMoved.ptr = movedImg;
         texMoved.pitch = pitchImg;
         texMoved.width = width;
         texMoved.height = height;
-        const float full = tex1<ADDR_MIRROR>(texMoved, g.u, g.v);
-        wv = g.interior ? wv : full;
+        const float full = tex1<ADDR_MIRROR>(texMoved, u, v);
+        if (!interior) {
+            g.t00 = g.t10 = g.t01 = g.t11 = full;
+            g.a = g.b = 0.0f;
+        }
     }
-    return wv;
 }
+__device__ __forceinline__ float lk_warp_finish(const LkGather& g) { return lerp4(g.t00, g.t10, g.t01, g.t11, g.a, g.b); }
 
 template <int HT>
 __global__ void __launch_bounds__(64)
@@ -589,30 +619,38 @@ __global__ void __launch_bounds__(64)
     const int T = rows + 2 * HALO;                    // input rows ry0 - HALO .. ry0 + rows - 1 + HALO
 
     float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;     // (warped + ref) of rows r-4 .. r
-    float d0 = 0, d1 = 0, d2 = 0;                     // (warped - ref) of rows r-2 .. r
+    float d0 = 0;                                     // (warped - ref) of row r-2: loaded two steps before it is used, not four
     float H[5][WIN];                                  // row sums of the five products, ring over rows
 #pragma unroll
     for (int k = 0; k < 5; k++)
 #pragma unroll
         for (int j = 0; j < WIN; j++) H[k][j] = 0.0f;
 
-    auto load_row = [&](int t, float& sv, float& dv) {
-        const int gy = lk_mirror_index(ry0 - HALO + t, height);
-        sv = row_ptr(F.sumIn, pitchSD, gy)[gxIn];
-        dv = row_ptr(F.diffIn, pitchSD, gy)[gxIn];
-    };
-    // two rows in flight ahead of the one being worked on
-    float sA, dA, sB, dB;
-    load_row(0, sA, dA);
-    load_row(min(1, T - 1), sB, dB);
+    auto load_sum = [&](int t, float& sv) { sv = *lk_at(F.sumIn, pitchSD, lk_mirror_index(ry0 - HALO + t, height), gxIn); };
+    auto load_diff = [&](int t, float& dv) { dv = *lk_at(F.diffIn, pitchSD, lk_mirror_index(ry0 - HALO + t, height), gxIn); };
+    // two rows in flight ahead of the one being worked on: the sum image's rows t + 1, t + 2 (the y derivative of row t - 2 needs
+    // rows up to t), the difference image's rows t - 1, t (It of row t - 2 is consumed two steps after its load)
+    float sA, sB, dA = 0, dB = 0;
+    load_sum(0, sA);
+    load_sum(min(1, T - 1), sB);
+#if !LK_DIFF_LATE
+    float d1 = 0, d2 = 0;
+    load_diff(0, dA);
+    load_diff(min(1, T - 1), dB);
+#endif
     LkGather pend;            // the previous output row's warp, issued and not yet consumed
     int pendY = -1;
     auto finish_pending = [&]() {
         if (pendY < 0) return;   // wave-uniform
-        const float wv = lk_warp_finish(F.moved, pitchImg, width, height, pend);
+        const float wv = lk_warp_finish(pend);
+#if LK_RV_REREAD
+        const float rv = *lk_at(refImg, pitchImg, pendY, colOutC);   // (A/B: a load in front of the row's stores -- slower)
+#else
+        const float rv = pend.rv;
+#endif
         if (outLane) {
-            row_ptr(F.sumOut, pitchSD, pendY)[colOutC] = wv + pend.rv;
-            row_ptr(F.diffOut, pitchSD, pendY)[colOutC] = wv - pend.rv;
+            *lk_at(F.sumOut, pitchSD, pendY, colOutC) = wv + rv;
+            *lk_at(F.diffOut, pitchSD, pendY, colOutC) = wv - rv;
         }
     };
 
@@ -623,15 +661,25 @@ __global__ void __launch_bounds__(64)
             if (t >= T) break;
             // rotate the raw-row rings; fetch row t + 2
             s0 = s1, s1 = s2, s2 = s3, s3 = s4, s4 = sA;
-            d0 = d1, d1 = d2, d2 = dA;
-            sA = sB, dA = dB;
-            load_row(min(t + 2, T - 1), sB, dB);
+#if LK_DIFF_LATE
+            d0 = dA, dA = dB;
+            sA = sB;
+            load_sum(min(t + 2, T - 1), sB);
+            load_diff(t, dB);
+#else
+            d0 = d1, d1 = d2, d2 = dA, dA = dB;
+            sA = sB;
+            load_sum(min(t + 2, T - 1), sB);
+            load_diff(min(t + 2, T - 1), dB);
+#endif
             if (t < 4) continue;   // the derivative of row r - 2 needs rows r - 4 .. r
             // this row's own flow and reference pixel: on their way while the sums are formed (every lane loads: clamped column)
             const int y = ry0 + t - 2 * HALO;                  // the row whose window this step completes (if t >= 2 HALO)
             const int yc = min(max(y, 0), height - 1);
-            float2 shift = row_ptr(F.flowIn, pitchShift, yc)[colOutC];
-            const float rvOwn = row_ptr(refImg, pitchImg, yc)[colOutC];
+            float2 shift = *lk_at(F.flowIn, pitchShift, yc, colOutC);
+#if !LK_RV_REREAD
+            const float rvOwn = *lk_at(refImg, pitchImg, yc, colOutC);
+#endif
             // products of image row r - 2 (opticalFlow.cu:116-131 on the sum image, as k_lkIterationFused step 2)
             const float xp1 = lk_wshl1(s2), xp2 = lk_wshl1(xp1), xm1 = lk_wshr1(s2), xm2 = lk_wshr1(xm1);
             float tx = xp2;
@@ -677,12 +725,15 @@ __global__ void __launch_bounds__(64)
             }
             if (F.sumOut) {   // wave-uniform
                 finish_pending();   // the previous row's gather: issued one row ago
-                lk_warp_issue(F.moved, pitchImg, width, height, colOutC, y, shift, rvOwn, pend, dW, dH);
+                lk_warp_issue(F.moved, pitchImg, width, height, colOutC, y, shift, outLane, pend, dW, dH);
+#if !LK_RV_REREAD
+                pend.rv = rvOwn;
+#endif
                 pendY = y;
             }
             shift.x *= outScale;
             shift.y *= outScale;
-            if (outLane) row_ptr(F.flowOut, pitchShift, y)[colOutC] = shift;
+            if (outLane) *lk_at(F.flowOut, pitchShift, y, colOutC) = shift;
         }
     }
     if (F.sumOut) finish_pending();
@@ -696,6 +747,9 @@ extern "C" int mfsr_lucasKanadeSweepBatch(int nFrames, const mfsr_lk_frame* fram
     if (halfWindowSize < 1 || halfWindowSize > 7 || width < 64 || height < 2 * (halfWindowSize + 2)) return MFSR_E_UNSUPPORTED;
     MFSR_REQUIRE((long long)pitchShift >= 8LL * width && (pitchShift & 7) == 0);
     MFSR_REQUIRE((long long)pitchImg >= 4LL * width && (pitchImg & 3) == 0 && (long long)pitchSD >= 4LL * width && (pitchSD & 3) == 0);
+    // (32-bit byte offsets inside every image, lk_at)
+    if ((long long)pitchShift * height >= (1LL << 32) || (long long)pitchImg * height >= (1LL << 32) || (long long)pitchSD * height >= (1LL << 32))
+        return MFSR_E_UNSUPPORTED;
     LkSweepBatch b;
     memset(&b, 0, sizeof(b));
     for (int i = 0; i < nFrames; i++) {
