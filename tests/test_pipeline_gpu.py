@@ -848,3 +848,36 @@ def test_frame_source_callback_equals_push_api():
         _, want = plain.process(frames[:available])
         assert torch.equal(got, want), available
         plain.close()
+
+
+def test_exact_reciprocal_division_equals_the_division():
+    """The flow-field, Lucas-Kanade and robustness kernels divide by the image dimensions with the reciprocal sequence the host
+    has proven exact for that divisor (common.hpp::mfsr_div, include/mfsr.h::mfsr_exactDivisionOk); MFSR_EXACT_DIV=0 keeps the
+    IEEE division.  The switch is read once per process, so each setting runs in its own: same flows, masks and image, bit for
+    bit, on a ragged RGGB burst and on a monochrome one (flow at another resolution than the mask)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from multi_frame_super_resolution_amd.pipeline import default_config
+from multi_frame_super_resolution_amd.synth import make_burst
+from tests.burst_compare import run_hip
+h = hashlib.sha256()
+for (W, H, N, s, mono) in ((392, 264, 5, 2, False), (320, 200, 3, 2, True)):
+    frames, _, _ = make_burst(W, H, N, scale=s, mono=mono, seed=99, max_shift=4.0)
+    r = run_hip(default_config(W, H, N, s, mono), frames)
+    for a in [r["out16"], r["img_out"], r["tw"]] + r["flows"] + r["masks"]:
+        h.update(np.ascontiguousarray(a).tobytes())
+print("SHA", h.hexdigest())
+''' % root
+    outs = []
+    for v in ("1", "0"):
+        env = dict(os.environ, MFSR_EXACT_DIV=v)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append([l for l in p.stdout.splitlines() if l.startswith("SHA")][0])
+    assert outs[0] == outs[1]
