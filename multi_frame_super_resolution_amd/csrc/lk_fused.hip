@@ -771,7 +771,22 @@ extern "C" int mfsr_lucasKanadeSweepBatch(int nFrames, const mfsr_lk_frame* fram
     // 27.6 us per frame: the wave count decides, the halo rows cost less than idle SIMDs)
     int band = (int)((long long)height * strips * nFrames / 8192);
     band = (band + 4) & ~7;
-    band = band < 8 ? 8 : (band > 64 ? 64 : band);
+    band = band < 8 ? 8 : (band > 32 ? 32 : band);   // (launches of several rounds: 12 .. 52 rows measure alike at 8K, 64 is 1 % slower)
+    {
+        // Round 4: the kernel holds 49 + 10 h registers, i.e. 8 / 7 / 6 / 5 / 4 / 4 / 4 waves per SIMD for h = 1 .. 7.  When all
+        // waves of the launch can be resident at once with bands of at most 64 rows, take the lowest such band: one round
+        // instead of a full one and a partly filled one, and fewer halo rows (1080 rows x 36 strips x 4 frames, h = 3: 26-row
+        // bands = 6048 waves for 6144 places: 104.5 against 107 us with 16-row bands; 27 .. 30: 105 .. 111 us,
+        // profiles/r04_lk_band_rule_ab.txt).  Larger launches keep the rule above.
+        static const int occ[8] = {0, 8, 7, 6, 5, 4, 4, 4};
+        const long long places = 1024LL * occ[h];
+        const long long maxBands = places / ((long long)strips * nFrames);
+        if (maxBands >= 1) {
+            int b = (int)((height + maxBands - 1) / maxBands);   // lowest band with ceil(height / band) <= maxBands
+            b = b < 8 ? 8 : b;
+            if (b <= 64) band = b;
+        }
+    }
     if (forceBand >= 8) band = forceBand;
     static const int xcdRemap = [] {
         const char* e = getenv("MFSR_LK_XCD");
