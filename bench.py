@@ -800,6 +800,17 @@ def main():
                                 # prices a STATIC mix and is good to a few percent)
                                 "all_fast_class_floor_ms": round(vi * 2.8 / (1024 * VALU_CLOCK_GHZ * 1e9) * 1e3, 4),
                                 "source": ent.get("source")}
+                        if k_ms > 0 and floor_ms > k_ms:
+                            # a floor above the measurement is refuted by it: the launch executes a lighter mix than the static
+                            # one (x4: the saturated / branchy paths).  The fraction is then taken against the bound no mix can
+                            # beat, every instruction at the fast class's cost, and the estimate is kept beside it.
+                            valu["static_mix_estimate_ms"] = valu["floor_ms"]
+                            valu["floor_ms"] = valu["all_fast_class_floor_ms"]
+                            valu["cycles_per_inst"] = 2.8
+                            valu["frac"] = round(valu["floor_ms"] / k_ms, 4)
+                            valu["floor_note"] = ("the class-weighted estimate of the STATIC mix lies above the measured launch, i.e. the "
+                                                  "executed mix is lighter: floor_ms / frac are the all-fast-class bound (2.8 cycles per "
+                                                  "instruction), the estimate is static_mix_estimate_ms")
                 elif ent is not None:
                     traffic = ent
             except Exception:
@@ -873,7 +884,10 @@ def main():
                 "isolated": ({"avg_launch_ms": round(isolated["avg_launch_ms"], 4), "launches_timed": isolated["launches_timed"],
                               "achieved": round(bytes_launch / (isolated["avg_launch_ms"] * 1e-3) / 1e9, 1),
                               "frac": round(bytes_launch / (isolated["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                              "valu_frac": (round(valu["floor_ms"] / isolated["avg_launch_ms"], 4) if valu else None)}
+                              # (against the same floor as valu.frac; the all-fast-class bound if the isolated launch beats the
+                              # static-mix estimate)
+                              "valu_frac": (round((valu["floor_ms"] if valu["floor_ms"] <= isolated["avg_launch_ms"]
+                                                   else valu["all_fast_class_floor_ms"]) / isolated["avg_launch_ms"], 4) if valu else None)}
                              if isolated else None),
                 "reference_structure": {
                     "bytes_per_launch": int(bytes_ref_launch), "achieved": round(achieved_ref, 1),
